@@ -1,0 +1,100 @@
+"""
+ctypes binding of libgpp_hip.so (C ABI declared in include/gpp.h).
+
+This module takes the place of the reference's operator-alias layer
+(/root/reference/keras_retinanet_3D/backend/tensorflow_backend.py:20-156): the layers of this
+package call hand-written HIP kernels through it instead of `tensorflow.*`.
+
+There is no CPU fallback.  If the shared library is missing, or no HIP device is present, the
+functions below raise; nothing silently routes around the kernels.
+"""
+
+import ctypes
+import os
+
+_LIB = None
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libgpp_hip.so'))
+CSRC_DIR = os.path.normpath(os.path.join(_HERE, '..', '..', 'csrc'))
+
+GPP_OK = 0
+_ERRORS = {
+    -1: 'GPP_ERR_BAD_ARG',
+    -2: 'GPP_ERR_WORKSPACE',
+    -3: 'GPP_ERR_ALIGN',
+    -4: 'GPP_ERR_UNSUPPORTED',
+}
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+c_int64 = ctypes.c_int64
+
+
+class GppError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    lib.gpp_version.restype = ctypes.c_char_p
+    lib.gpp_version.argtypes = []
+    lib.gpp_poll_workspace_bytes.restype = c_int
+    lib.gpp_poll_workspace_bytes.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_size_t)]
+    lib.gpp_poll_f32.restype = c_int
+    lib.gpp_poll_f32.argtypes = [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 4 + \
+        [c_void_p, c_size_t, c_void_p]
+
+
+def build(verbose=False):
+    """ Compile libgpp_hip.so in-tree with hipcc for gfx950 (works without a GPU). """
+    import subprocess
+    cmd = ['make', '-C', CSRC_DIR, '-j4']
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise GppError('building libgpp_hip.so failed (see output above)')
+
+
+def lib():
+    """ The loaded library.  Raises GppError when it has not been built. """
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise GppError('{} not found: build it with `make -C {}` (or __graft_entry__.build()); '
+                           'there is no CPU fallback for the HIP path'.format(LIB_PATH, CSRC_DIR))
+        handle = ctypes.CDLL(LIB_PATH)
+        _declare(handle)
+        _LIB = handle
+    return _LIB
+
+
+def check(rc, what=''):
+    if rc == GPP_OK:
+        return
+    if rc < 0:
+        raise GppError('{} failed: {}'.format(what or 'gpp call', _ERRORS.get(rc, rc)))
+    raise GppError('{} failed: hipError_t {}'.format(what or 'gpp call', rc))
+
+
+def require_device():
+    """ torch.device('cuda', current) or raise: the product path needs an MI355X. """
+    import torch
+    if not torch.cuda.is_available():
+        raise GppError('no HIP device visible: the ground-plane-polling hot path runs only on the GPU '
+                       '(there is no CPU fallback; the CPU oracle under oracle/ is test infrastructure)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """ Raw device pointer of a contiguous torch tensor (or None). """
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'gpp kernels need dense tensors'
+    return ctypes.c_void_p(t.data_ptr())
