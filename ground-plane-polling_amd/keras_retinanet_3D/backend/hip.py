@@ -32,8 +32,35 @@ c_size_t = ctypes.c_size_t
 c_int64 = ctypes.c_int64
 
 
+GPP_BF16 = 1
+GPP_F16 = 2
+GPP_MAX_GROUPS = 5
+
+
 class GppError(RuntimeError):
     pass
+
+
+class ConvGroup(ctypes.Structure):
+    """ gpp_conv_group (include/gpp.h) """
+    _fields_ = [('in_off', c_int64), ('in_bstride', c_int64), ('out_off', c_int64), ('out_bstride', c_int64),
+                ('res_off', c_int64), ('res_bstride', c_int64),
+                ('H_in', ctypes.c_int32), ('W_in', ctypes.c_int32), ('H_out', ctypes.c_int32), ('W_out', ctypes.c_int32),
+                ('H_res', ctypes.c_int32), ('W_res', ctypes.c_int32), ('tile_start', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
+class ConvDesc(ctypes.Structure):
+    """ gpp_conv_desc (include/gpp.h) """
+    _fields_ = [('inp', c_void_p), ('weight', c_void_p), ('bias', c_void_p), ('residual', c_void_p),
+                ('out', c_void_p), ('zero_page', c_void_p),
+                ('dtype', ctypes.c_int32), ('out_f32', ctypes.c_int32),
+                ('batch', ctypes.c_int32), ('C_in', ctypes.c_int32), ('C_out', ctypes.c_int32),
+                ('KH', ctypes.c_int32), ('KW', ctypes.c_int32), ('stride', ctypes.c_int32),
+                ('pad_top', ctypes.c_int32), ('pad_left', ctypes.c_int32),
+                ('in_pitch', ctypes.c_int32), ('out_pitch', ctypes.c_int32), ('res_pitch', ctypes.c_int32),
+                ('weight_rows', ctypes.c_int32), ('relu', ctypes.c_int32), ('n_groups', ctypes.c_int32),
+                ('groups', ConvGroup * GPP_MAX_GROUPS)]
 
 
 def _declare(lib):
@@ -44,6 +71,10 @@ def _declare(lib):
     lib.gpp_poll_f32.restype = c_int
     lib.gpp_poll_f32.argtypes = [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 4 + \
         [c_void_p, c_size_t, c_void_p]
+    lib.gpp_conv2d_igemm.restype = c_int
+    lib.gpp_conv2d_igemm.argtypes = [ctypes.POINTER(ConvDesc), c_void_p]
+    lib.gpp_conv2d_flops.restype = c_int
+    lib.gpp_conv2d_flops.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_double)]
 
 
 def build(verbose=False):

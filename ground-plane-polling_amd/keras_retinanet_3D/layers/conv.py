@@ -1,0 +1,127 @@
+"""
+Host side of the HIP convolution kernels (csrc/conv_igemm.hip, C ABI gpp_conv2d_igemm).
+
+Plays the role of keras.layers.Conv2D (+ folded frozen BatchNormalization, Activation('relu'),
+Add and layers.UpsampleLike) for the graph of
+/root/reference/keras_retinanet_3D/models/retinanet.py:24-205 and the keras_resnet backbone
+(models/resnet.py:88-93): it only builds gpp_conv_desc records over torch device buffers
+and enqueues the kernel; no arithmetic happens in Python or in torch.
+"""
+
+import ctypes
+
+import numpy as np
+
+from ..backend import hip
+
+
+def torch_dtype(dtype):
+    import torch
+    return {'bf16': torch.bfloat16, 'f16': torch.float16}[dtype]
+
+
+def gpp_dtype(dtype):
+    return {'bf16': hip.GPP_BF16, 'f16': hip.GPP_F16}[dtype]
+
+
+class FMap(object):
+    """ A feature map living inside a torch buffer: pixel (b, y, x) starts at element
+    off + b*bstride + (y*W + x)*pitch and has C contiguous channels. """
+
+    def __init__(self, buf, B, H, W, C, off=0, bstride=None, pitch=None):
+        self.buf, self.B, self.H, self.W, self.C = buf, int(B), int(H), int(W), int(C)
+        self.off = int(off)
+        self.pitch = int(C if pitch is None else pitch)
+        self.bstride = int(self.H * self.W * self.pitch if bstride is None else bstride)
+
+    @classmethod
+    def empty(cls, B, H, W, C, dtype, device):
+        import torch
+        return cls(torch.empty((B, H, W, C), dtype=dtype, device=device), B, H, W, C)
+
+    def dense(self):
+        """ (B, H, W, C) torch view of the map (needs pitch*W*H <= bstride). """
+        import torch
+        return torch.as_strided(self.buf.view(-1), (self.B, self.H, self.W, self.C),
+                                (self.bstride, self.W * self.pitch, self.pitch, 1), self.off)
+
+
+def pack_weight(kernel_hwio, dtype, device):
+    """ Keras HWIO float32 kernel (KH, KW, C_in, C_out) -> device tensor
+    [C_out rounded up to 128][KH*KW*C_in] in the compute type, K ordered (kh, kw, c_in). """
+    import torch
+    k = torch.as_tensor(np.ascontiguousarray(kernel_hwio, dtype=np.float32))
+    KH, KW, Cin, Cout = k.shape
+    rows = ((Cout + 127) // 128) * 128
+    w = torch.zeros((rows, KH * KW * Cin), dtype=torch.float32)
+    w[:Cout] = k.permute(3, 0, 1, 2).reshape(Cout, KH * KW * Cin)
+    return w.to(torch_dtype(dtype)).to(device).contiguous()
+
+
+_ZERO_PAGES = {}
+
+
+def zero_page(device):
+    import torch
+    key = str(device)
+    if key not in _ZERO_PAGES:
+        _ZERO_PAGES[key] = torch.zeros((256,), dtype=torch.uint8, device=device)
+    return _ZERO_PAGES[key]
+
+
+def same_pad(in_size, k, stride):
+    """ TF 'same' padding: (out, pad_before). """
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + k - in_size, 0)
+    return out, total // 2
+
+
+def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=(0, 0), relu=False,
+              residuals=None, dtype='bf16', out_f32=False):
+    """ Build a gpp_conv_desc.  inputs / outputs / residuals are lists of FMap (one per group,
+    all groups share weights; every list member must live in the same torch buffer). """
+    d = hip.ConvDesc()
+    esz = 2
+    d.inp = inputs[0].buf.data_ptr()
+    d.weight = weight.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.out = outputs[0].buf.data_ptr()
+    d.zero_page = zero_page(inputs[0].buf.device).data_ptr()
+    d.residual = residuals[0].buf.data_ptr() if residuals else None
+    d.dtype = gpp_dtype(dtype)
+    d.out_f32 = int(out_f32)
+    d.batch = inputs[0].B
+    d.C_in, d.C_out, d.KH, d.KW, d.stride = C_in, C_out, KH, KW, stride
+    d.pad_top, d.pad_left = pad
+    d.in_pitch, d.out_pitch = inputs[0].pitch, outputs[0].pitch
+    d.res_pitch = residuals[0].pitch if residuals else 0
+    d.weight_rows = int(weight.shape[0])
+    d.relu = int(relu)
+    d.n_groups = len(inputs)
+    assert 1 <= len(inputs) <= hip.GPP_MAX_GROUPS and len(outputs) == len(inputs)
+    assert int(weight.shape[1]) == KH * KW * C_in
+    for g, (fi, fo) in enumerate(zip(inputs, outputs)):
+        assert fi.buf.data_ptr() == inputs[0].buf.data_ptr() and fo.buf.data_ptr() == outputs[0].buf.data_ptr()
+        assert fi.pitch == d.in_pitch and fo.pitch == d.out_pitch and fi.B == d.batch and fo.B == d.batch
+        G = d.groups[g]
+        G.in_off, G.in_bstride = fi.off, fi.bstride
+        G.out_off, G.out_bstride = fo.off, fo.bstride
+        G.H_in, G.W_in, G.H_out, G.W_out = fi.H, fi.W, fo.H, fo.W
+        if residuals:
+            fr = residuals[g]
+            assert fr.buf.data_ptr() == residuals[0].buf.data_ptr() and fr.pitch == d.res_pitch
+            G.res_off, G.res_bstride, G.H_res, G.W_res = fr.off, fr.bstride, fr.H, fr.W
+        else:
+            G.H_res, G.W_res = fo.H, fo.W
+    del esz
+    return d
+
+
+def run_conv(desc):
+    hip.check(hip.lib().gpp_conv2d_igemm(ctypes.byref(desc), hip.stream_ptr()), 'gpp_conv2d_igemm')
+
+
+def conv_flops(desc):
+    f = ctypes.c_double(0.0)
+    hip.check(hip.lib().gpp_conv2d_flops(ctypes.byref(desc), ctypes.byref(f)), 'gpp_conv2d_flops')
+    return f.value

@@ -65,6 +65,77 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
                  float* keypoints, float* keyplanes, float* residuals, int32_t* best_idx,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Element types of activations / weights of the convolution kernels.
+ * ---------------------------------------------------------------------------------------- */
+#define GPP_BF16 1   /* bfloat16 storage, float32 MFMA accumulation (default compute type) */
+#define GPP_F16 2    /* IEEE half storage, float32 MFMA accumulation */
+
+/* ------------------------------------------------------------------------------------------
+ * 2-D convolution, NHWC, implicit GEMM on MFMA (no im2col buffer), fused epilogue
+ *     out = act( conv(in, weight) + bias [+ nearest_resize(residual)] )
+ * Replaces every Conv2D (+ frozen BatchNormalization folded into weight/bias, + ReLU, + Add,
+ * + UpsampleLike) of the graph built by models/retinanet.py:24-205 (heads :24-167, FPN
+ * :170-205; UpsampleLike layers/_misc.py:90-100) and of the third-party keras_resnet
+ * bottleneck stack instantiated at models/resnet.py:88-93, except the 3-channel stem.
+ *
+ * One launch covers up to GPP_MAX_GROUPS independent feature maps that share the weights
+ * (the five pyramid levels of a head layer, retinanet.py:257-281), each described by a
+ * gpp_conv_group.  GEMM view per group: M = batch*H_out*W_out output pixels, N = C_out,
+ * K = KH*KW*C_in, K ordered (kh, kw, c_in).
+ *
+ * Layouts (element = 2 bytes, GPP_BF16 or GPP_F16)
+ *   in        pixel (b, y, x) of a group at  in + in_off + b*in_bstride + (y*W_in + x)*in_pitch,
+ *             C_in contiguous channels there (in_pitch >= C_in lets a channel slice be read)
+ *   weight    [C_out rounded up to a multiple of 128][KH*KW*C_in], K contiguous; rows >= C_out
+ *             must exist (zero) -- weight_rows states how many rows are allocated
+ *   bias      [C_out] float32 (NULL = none)
+ *   residual  same addressing as out with res_* fields; when H_res/W_res differ from
+ *             H_out/W_out the residual is read with TF nearest-neighbour resize semantics
+ *             src = min(floor(dst * in/out), in-1)  (tf.image.resize_images, align_corners=False)
+ *   out       element type = dtype, or float32 when out_f32 != 0
+ *   zero_page >= 256 bytes of zeros (source of out-of-image taps)
+ * Requirements: C_in % 64 == 0; C_out % 4 == 0; in_pitch, out_pitch, res_pitch multiples of 8
+ * (4 for float32 out); all base pointers 16-byte aligned; stride in {1, 2}.
+ * Padding is explicit (pad_top, pad_left); bottom/right padding is implied by H_out/W_out
+ * (this covers Keras 'same' at stride 1, TF's asymmetric 'same' at stride 2, and
+ * ZeroPadding2D + 'valid').
+ * ---------------------------------------------------------------------------------------- */
+#define GPP_MAX_GROUPS 5
+
+typedef struct gpp_conv_group {
+    int64_t in_off, in_bstride;     /* elements */
+    int64_t out_off, out_bstride;
+    int64_t res_off, res_bstride;
+    int32_t H_in, W_in, H_out, W_out;
+    int32_t H_res, W_res;
+    int32_t tile_start;             /* filled in by the library */
+    int32_t reserved;
+} gpp_conv_group;
+
+typedef struct gpp_conv_desc {
+    const void* in;
+    const void* weight;
+    const float* bias;
+    const void* residual;
+    void* out;
+    const void* zero_page;
+    int32_t dtype;                  /* GPP_BF16 | GPP_F16 */
+    int32_t out_f32;
+    int32_t batch, C_in, C_out, KH, KW, stride, pad_top, pad_left;
+    int32_t in_pitch, out_pitch, res_pitch;   /* elements per pixel */
+    int32_t weight_rows;
+    int32_t relu;
+    int32_t n_groups;
+    gpp_conv_group groups[GPP_MAX_GROUPS];
+} gpp_conv_desc;
+
+int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream);
+
+/* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
+int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
+
 #ifdef __cplusplus
 }
 #endif
