@@ -1,0 +1,134 @@
+"""
+GPU numerics of the implicit-GEMM convolution kernel (C ABI gpp_conv2d_igemm) against a plain
+PyTorch float32 reference of the same op on the CPU.  Inputs/weights are rounded to the
+16-bit compute type first, so the only differences are float32 accumulation order and the
+final rounding of the output to 16 bits:  |err| <= 2^-8 * |ref| + 1e-3 (bf16), 2^-10 (f16),
+1e-4 relative for float32 outputs.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from keras_retinanet_3D.layers import conv as C
+
+pytestmark = pytest.mark.gpu
+
+
+def tf_nearest(x, oh, ow):
+    ih, iw = x.shape[1:3]
+    ys = torch.clamp(torch.floor(torch.arange(oh, dtype=torch.float32) * (np.float32(ih) / np.float32(oh))).long(), max=ih - 1)
+    xs = torch.clamp(torch.floor(torch.arange(ow, dtype=torch.float32) * (np.float32(iw) / np.float32(ow))).long(), max=iw - 1)
+    return x[:, ys][:, :, xs]
+
+
+def reference(x, k, bias, stride, pad_t, pad_l, oh, ow, relu, res):
+    """ x (B,H,W,Cin) f32, k HWIO f32 -> (B,oh,ow,Cout) f32 """
+    B, H, W, _ = x.shape
+    KH, KW = k.shape[:2]
+    pad_b = max((oh - 1) * stride + KH - H - pad_t, 0)
+    pad_r = max((ow - 1) * stride + KW - W - pad_l, 0)
+    xp = F.pad(x.permute(0, 3, 1, 2), (pad_l, pad_r, pad_t, pad_b))
+    y = F.conv2d(xp, k.permute(3, 2, 0, 1), bias, stride=stride)[:, :, :oh, :ow].permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + (tf_nearest(res, oh, ow) if tuple(res.shape[1:3]) != (oh, ow) else res)
+    return torch.relu(y) if relu else y
+
+
+CASES = [
+    # name, B, H, W, Cin, Cout, K, stride, pad(t,l), out(h,w) or None (same), relu, residual (None|'same'|(h,w)), out_f32
+    ('1x1', 2, 13, 17, 64, 128, 1, 1, (0, 0), None, True, None, False),
+    ('1x1_s2', 2, 13, 18, 128, 256, 1, 2, (0, 0), (7, 9), False, None, False),
+    ('3x3', 2, 13, 17, 64, 64, 3, 1, (1, 1), None, True, None, False),
+    ('3x3_wide', 1, 26, 31, 128, 512, 3, 1, (1, 1), None, False, 'same', False),
+    ('3x3_s2_tfsame', 2, 13, 42, 64, 128, 3, 2, None, None, False, None, False),
+    ('1x1_res_up', 2, 26, 31, 64, 128, 1, 1, (0, 0), None, False, (13, 16), False),
+    ('1x1_res_up_nonint', 1, 51, 67, 64, 128, 1, 1, (0, 0), None, False, (26, 34), False),
+    ('head_out36_f32', 2, 9, 11, 128, 36, 3, 1, (1, 1), None, False, None, True),
+    ('head_out96_f32', 1, 9, 11, 256, 96, 3, 1, (1, 1), None, False, None, True),
+    ('head_out144_f32', 1, 9, 11, 64, 144, 3, 1, (1, 1), None, False, None, True),
+    ('bottleneck_2c', 1, 26, 21, 64, 256, 1, 1, (0, 0), None, True, 'same', False),
+    ('deepK', 1, 7, 9, 1024, 128, 3, 1, (1, 1), None, True, None, False),
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_matches_torch_fp32(case, dtype):
+    name, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, out_f32 = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    tdt = C.torch_dtype(dtype)
+    dev = torch.device('cuda')
+    x = torch.randn((B, H, W, Cin), generator=g).to(tdt)
+    k = (torch.randn((K, K, Cin, Cout), generator=g) * (2.0 / (K * K * Cin)) ** 0.5).to(tdt)
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    if pad is None:
+        oh, pt = C.same_pad(H, K, stride)
+        ow, pl = C.same_pad(W, K, stride)
+    else:
+        pt, pl = pad
+        oh, ow = out_hw if out_hw else (H, W)
+    res = None
+    if resmode == 'same':
+        res = torch.randn((B, oh, ow, Cout), generator=g).to(tdt)
+    elif resmode is not None:
+        res = torch.randn((B, resmode[0], resmode[1], Cout), generator=g).to(tdt)
+    ref = reference(x.float(), k.float(), bias, stride, pt, pl, oh, ow, relu, None if res is None else res.float())
+
+    xin = C.FMap(x.to(dev).contiguous(), B, H, W, Cin)
+    out = C.FMap.empty(B, oh, ow, Cout, torch.float32 if out_f32 else tdt, dev)
+    out.buf.fill_(float('nan'))
+    w = C.pack_weight(k.float().numpy(), dtype, dev)
+    rmap = None if res is None else [C.FMap(res.to(dev).contiguous(), B, res.shape[1], res.shape[2], Cout)]
+    d = C.conv_desc([xin], [out], w, bias.to(dev), K, K, Cin, Cout, stride=stride, pad=(pt, pl), relu=relu,
+                    residuals=rmap, dtype=dtype, out_f32=out_f32)
+    C.run_conv(d)
+    got = out.buf.float().cpu()
+    assert torch.isfinite(got).all()
+    eps = 1e-4 if out_f32 else (2.0 ** -8 if dtype == 'bf16' else 2.0 ** -10)
+    err = (got - ref).abs()
+    tol = eps * ref.abs() + 1e-3
+    assert bool((err <= tol).all()), 'max err {} at ref {}'.format(err.max().item(), ref.flatten()[err.argmax()].item())
+    assert abs(C.conv_flops(d) - 2.0 * B * oh * ow * K * K * Cin * Cout) < 1.0
+
+
+def test_grouped_pyramid_launch_and_channel_slices():
+    """ five feature maps of different sizes in one launch, inputs read as a channel slice of a
+    wider tensor, outputs written at level offsets of one (B, sum(HW), C) pyramid tensor """
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cwide, Cout = 2, 64, 192, 128
+    shapes = [(13, 21), (7, 11), (4, 6), (2, 3), (1, 2)]
+    total = sum(h * w for h, w in shapes)
+    xin = torch.randn((B, total, Cwide), generator=g).to(torch.bfloat16)
+    k = (torch.randn((3, 3, Cin, Cout), generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    xd = xin.to(dev).contiguous()
+    od = torch.full((B, total, Cout), float('nan'), dtype=torch.bfloat16, device=dev)
+    ins, outs, off = [], [], 0
+    for h, w in shapes:
+        ins.append(C.FMap(xd, B, h, w, Cin, off=off * Cwide + 64, bstride=total * Cwide, pitch=Cwide))
+        outs.append(C.FMap(od, B, h, w, Cout, off=off * Cout, bstride=total * Cout))
+        off += h * w
+    d = C.conv_desc(ins, outs, C.pack_weight(k.float().numpy(), 'bf16', dev), bias.to(dev), 3, 3, Cin, Cout,
+                    pad=(1, 1), relu=True)
+    C.run_conv(d)
+    got = od.float().cpu()
+    off = 0
+    for h, w in shapes:
+        x = xin[:, off:off + h * w, 64:128].float().reshape(B, h, w, Cin)
+        ref = reference(x, k.float(), bias, 1, 1, 1, h, w, True, None).reshape(B, h * w, Cout)
+        err = (got[:, off:off + h * w] - ref).abs()
+        assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-3).all())
+        off += h * w
+
+
+def test_conv_rejects_bad_descriptors():
+    from keras_retinanet_3D.backend import hip
+    dev = torch.device('cuda')
+    x = C.FMap.empty(1, 4, 4, 48, torch.bfloat16, dev)       # C_in not a multiple of 64
+    o = C.FMap.empty(1, 4, 4, 64, torch.bfloat16, dev)
+    w = torch.zeros((128, 48), dtype=torch.bfloat16, device=dev)
+    d = C.conv_desc([x], [o], w, None, 1, 1, 48, 64)
+    with pytest.raises(hip.GppError):
+        C.run_conv(d)
