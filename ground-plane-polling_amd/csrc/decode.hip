@@ -1,0 +1,337 @@
+// Detection decode on gfx950: sigmoid + orientation fold + score threshold compaction, then per
+// image sort, greedy NMS, top-k, full box / dimension decode of the survivors and -1 padding.
+// The head tensors never leave the device between the convolutions and the polling kernel.
+//
+// Replaces (citations relative to /root/reference/keras_retinanet_3D):
+//   Activation('sigmoid')                         models/retinanet.py:72-73
+//   RegressBoxes.call + bbox_transform_inv        layers/_misc.py:133-141, backend/common.py:43-81
+//   RegressDims + dim_transform_inv               layers/_misc.py:186-187, backend/common.py:23-40
+//   filter_detections (default path: nms=True, class_specific_filter=True,
+//   orientation_specific_filter=False, num_classes == 1)   layers/filter_detections.py:18-189
+//   incl. tf.image.non_max_suppression, tf.nn.top_k, tf.pad
+//
+// Exactness: this file is compiled with -ffp-contract=off and evaluates the same float32
+// operation sequence as oracle/decode_np.py, including a Cephes-style expf (the algorithm of
+// Eigen's packet exp that TF's CPU sigmoid uses), so scores, boxes and the NMS decisions agree
+// with the oracle bit for bit.  Ordering rules: candidates by (score desc, anchor index asc);
+// NMS suppresses IoU > threshold (strict), zero-area boxes never overlap.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gpp.h"
+
+namespace {
+
+// ---- Cephes expf, one float32 operation at a time (mirrors oracle/decode_np.py:cephes_expf)
+__device__ __forceinline__ float cephes_expf(float x)
+{
+    x = fminf(fmaxf(x, -88.3762626647949f), 88.3762626647949f);
+    float fx = floorf(x * 1.44269504088896341f + 0.5f);
+    x = (x - fx * 0.693359375f) - fx * -2.12194440e-4f;
+    const float z = x * x;
+    float y = 1.9875691500e-4f;
+    y = y * x + 1.3981999507e-3f;
+    y = y * x + 8.3334519073e-3f;
+    y = y * x + 4.1665795894e-2f;
+    y = y * x + 1.6666665459e-1f;
+    y = y * x + 5.0000001201e-1f;
+    y = (y * z + x) + 1.0f;
+    return ldexpf(y, (int)fx);
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + cephes_expf(-x)); }
+
+struct Folded { float score; int orient; float sign; };
+
+// filter_detections.py:78-82,123-125 and _misc.py:134-136 on the 8 sigmoid scores of one anchor
+__device__ __forceinline__ Folded fold8(const float* l)
+{
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = sigmoidf(l[k]);
+    int am = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (s[k] > s[am]) am = k;          // first maximum
+    Folded f;
+    f.sign = (am < 4) ? -1.0f : 1.0f;
+    float best = fmaxf(s[0], s[4]);
+    int bo = 0;
+#pragma unroll
+    for (int o = 1; o < 4; ++o) {
+        const float v = fmaxf(s[o], s[o + 4]);
+        if (v > best) { best = v; bo = o; }
+    }
+    f.score = best;
+    f.orient = bo;
+    return f;
+}
+
+__global__ __launch_bounds__(256) void candidates_kernel(const float* __restrict__ cls, int64_t n_anchors, int64_t key_stride,
+                                                         float thr, unsigned long long* __restrict__ keys,
+                                                         int32_t* __restrict__ counts)
+{
+    const int b = blockIdx.y;
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= n_anchors) return;
+    const float4* src = (const float4*)(cls + ((int64_t)b * n_anchors + a) * 8);
+    const float4 v0 = src[0], v1 = src[1];
+    const float l[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const Folded f = fold8(l);
+    if (f.score > thr) {
+        const int slot = atomicAdd(&counts[b], 1);
+        keys[(int64_t)b * key_stride + slot] =
+            ((unsigned long long)__float_as_uint(f.score) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)a);
+    }
+}
+
+__constant__ float kBoxMean[12] = {-0.0373f, -0.0165f, 0.0373f, 0.0171f, -0.0286f, -0.0478f,
+                                   0.2929f, 0.0114f, 0.0288f, -0.0589f, 0.2932f, -0.0007f};   // _misc.py:115
+__constant__ float kBoxStd[12] = {0.1957f, 0.1896f, 0.1957f, 0.1897f, 0.1967f, 0.2034f,
+                                  0.2046f, 0.1898f, 0.1964f, 0.2052f, 0.2048f, 0.1903f};      // _misc.py:117
+__constant__ float kDimMean[3] = {1.6570f, 1.7999f, 4.2907f};                                   // _misc.py:168
+__constant__ float kDimStd[3] = {0.2681f, 0.2243f, 0.6281f};                                    // _misc.py:170
+
+struct Layout { int fused; int nba; };   // fused: regression stored (P, [4A | 2A | 2A | 2A | 2A]) per pixel
+
+// regression value j (0..11) of anchor a of image b
+__device__ __forceinline__ float reg_at(const float* reg, Layout L, int64_t n_anchors, int b, int64_t a, int j)
+{
+    if (!L.fused) return reg[((int64_t)b * n_anchors + a) * 12 + j];
+    const int64_t p = a / L.nba;
+    const int k = (int)(a - p * L.nba);
+    const int A = L.nba;
+    const int c = (j < 4) ? (k * 4 + j) : (4 * A + ((j - 4) >> 1) * 2 * A + k * 2 + ((j - 4) & 1));
+    return reg[((int64_t)b * (n_anchors / A) + p) * (12 * A) + c];
+}
+
+// backend/common.py:62-77
+__device__ __forceinline__ float box_coord(int j, const float4 an, float delta, float sign)
+{
+    const float w = an.z - an.x, h = an.w - an.y;
+    const float t = delta * kBoxStd[j] + kBoxMean[j];
+    switch (j) {
+    case 0: return an.x + t * w;
+    case 1: return an.y + t * h;
+    case 2: return an.z + t * w;
+    case 3: return an.w + t * h;
+    case 4: return an.x + t * w;
+    case 5: return an.w + t * h;
+    case 6: return (an.x + an.z) / 2.0f + (t * w) * sign;
+    case 7: return an.w + t * h;
+    case 8: return an.z + t * w;
+    case 9: return an.w + t * h;
+    case 10: return (an.x + an.z) / 2.0f + (t * w) * sign;
+    default: return an.y + t * h;
+    }
+}
+
+// tf.image.non_max_suppression's overlap test (corners min/max-normalised, zero area -> no overlap)
+__device__ __forceinline__ bool iou_above(const float4 a, const float4 b, float thr)
+{
+    const float ay0 = fminf(a.x, a.z), ax0 = fminf(a.y, a.w), ay1 = fmaxf(a.x, a.z), ax1 = fmaxf(a.y, a.w);
+    const float by0 = fminf(b.x, b.z), bx0 = fminf(b.y, b.w), by1 = fmaxf(b.x, b.z), bx1 = fmaxf(b.y, b.w);
+    const float area_a = (ay1 - ay0) * (ax1 - ax0);
+    const float area_b = (by1 - by0) * (bx1 - bx0);
+    if (area_a <= 0.0f || area_b <= 0.0f) return false;
+    const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.0f);
+    const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.0f);
+    const float inter = ih * iw;
+    return inter / ((area_a + area_b) - inter) > thr;
+}
+
+constexpr int kNmsThreads = 1024;
+constexpr int kLdsKeys = 8192;
+
+__device__ __forceinline__ void bitonic_desc(unsigned long long* k, int n, int tid)
+{
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < (n >> 1); t += kNmsThreads) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = k[lo], b = k[hi];
+                if ((a < b) == desc) { k[lo] = b; k[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kNmsThreads) void nms_kernel(
+    unsigned long long* __restrict__ keys, const int32_t* __restrict__ counts, int64_t key_stride,
+    const float* __restrict__ cls, const float* __restrict__ reg, const float* __restrict__ regdim,
+    const float4* __restrict__ anchors, int64_t n_anchors, Layout L, float iou_thr, int max_det,
+    float* __restrict__ o_boxes, float* __restrict__ o_dims, float* __restrict__ o_scores,
+    int32_t* __restrict__ o_labels, int32_t* __restrict__ o_orient, int32_t* __restrict__ o_anchor,
+    float4* __restrict__ ws_boxes, unsigned char* __restrict__ ws_alive)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
+    unsigned long long* lkeys = (unsigned long long*)nms_smem;
+    __shared__ int s_next;
+    __shared__ int s_kept[128];
+    __shared__ float4 s_box;
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int K = min(counts[b], (int)n_anchors);
+    unsigned long long* gkeys = keys + (int64_t)b * key_stride;
+    float4* boxes4 = ws_boxes + (int64_t)b * n_anchors;
+    unsigned char* alive = ws_alive + (int64_t)b * n_anchors;
+
+    // ---- sort candidates: (score desc, anchor asc)
+    int n = 1;
+    while (n < K) n <<= 1;
+    unsigned long long* sk;
+    if (n <= kLdsKeys) {
+        for (int t = tid; t < n; t += kNmsThreads) lkeys[t] = (t < K) ? gkeys[t] : 0ull;
+        bitonic_desc(lkeys, n, tid);
+        sk = lkeys;
+    } else {
+        for (int t = K + tid; t < n; t += kNmsThreads) gkeys[t] = 0ull;
+        bitonic_desc(gkeys, n, tid);
+        sk = gkeys;
+    }
+
+    // ---- x1 y1 x2 y2 of every candidate (filter_detections.py:58,61 uses boxes[:, :4])
+    for (int t = tid; t < K; t += kNmsThreads) {
+        const unsigned long long key = sk[t];
+        const int64_t a = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+        const float4 an = anchors[a];
+        float4 bx;
+        bx.x = box_coord(0, an, reg_at(reg, L, n_anchors, b, a, 0), 0.0f);
+        bx.y = box_coord(1, an, reg_at(reg, L, n_anchors, b, a, 1), 0.0f);
+        bx.z = box_coord(2, an, reg_at(reg, L, n_anchors, b, a, 2), 0.0f);
+        bx.w = box_coord(3, an, reg_at(reg, L, n_anchors, b, a, 3), 0.0f);
+        boxes4[t] = bx;
+        alive[t] = 1;
+    }
+    __syncthreads();
+
+    // ---- greedy NMS in score order
+    int kept = 0, cursor = 0;
+    while (kept < max_det && cursor < K) {
+        if (tid < 64) {                                   // wavefront 0 finds the next live candidate
+            int found = -1;
+            for (int base = cursor; base < K && found < 0; base += 64) {
+                const int j = base + tid;
+                const unsigned long long m = __ballot(j < K && alive[j] != 0);
+                if (m) found = base + __ffsll((long long)m) - 1;
+            }
+            if (tid == 0) {
+                s_next = found;
+                if (found >= 0) { s_kept[kept] = found; s_box = boxes4[found]; }
+            }
+        }
+        __syncthreads();
+        const int i = s_next;
+        if (i < 0) break;
+        const float4 bi = s_box;
+        ++kept;
+        for (int j = i + 1 + tid; j < K; j += kNmsThreads)
+            if (alive[j] && iou_above(bi, boxes4[j], iou_thr)) alive[j] = 0;
+        cursor = i + 1;
+        __syncthreads();
+    }
+
+    // ---- outputs: survivors in score order (tf.nn.top_k of an already sorted list is the identity),
+    //      then -1 padding (filter_detections.py:159-177)
+    for (int t = tid; t < max_det; t += kNmsThreads) {
+        float* ob = o_boxes + ((int64_t)b * max_det + t) * 12;
+        float* od = o_dims + ((int64_t)b * max_det + t) * 3;
+        const int64_t row = (int64_t)b * max_det + t;
+        if (t < kept) {
+            const unsigned long long key = sk[s_kept[t]];
+            const int64_t a = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+            const float4* src = (const float4*)(cls + ((int64_t)b * n_anchors + a) * 8);
+            const float4 v0 = src[0], v1 = src[1];
+            const float l[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const Folded f = fold8(l);
+            const float4 an = anchors[a];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) ob[j] = box_coord(j, an, reg_at(reg, L, n_anchors, b, a, j), f.sign);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) od[j] = regdim[((int64_t)b * n_anchors + a) * 3 + j] * kDimStd[j] + kDimMean[j];
+            o_scores[row] = f.score;
+            o_labels[row] = 0;
+            o_orient[row] = f.orient;
+            if (o_anchor) o_anchor[row] = (int32_t)a;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) ob[j] = -1.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) od[j] = -1.0f;
+            o_scores[row] = -1.0f;
+            o_labels[row] = -1;
+            o_orient[row] = -1;
+            if (o_anchor) o_anchor[row] = -1;
+        }
+    }
+}
+
+inline int64_t pow2_ceil(int64_t v)
+{
+    int64_t n = 1;
+    while (n < v) n <<= 1;
+    return n;
+}
+
+}  // namespace
+
+extern "C" int gpp_detect_workspace_bytes(int B, int64_t n_anchors, size_t* bytes)
+{
+    if (!bytes || B < 0 || n_anchors <= 0) return GPP_ERR_BAD_ARG;
+    const size_t keys = (size_t)pow2_ceil(n_anchors) * 8;
+    const size_t boxes = (size_t)n_anchors * 16;
+    const size_t alive = ((size_t)n_anchors + 15) / 16 * 16;
+    *bytes = 256 + (size_t)B * (keys + boxes + alive);
+    return GPP_OK;
+}
+
+extern "C" int gpp_detect_f32(const float* cls_logits, const float* regression, const float* regression_dim,
+                              const float* anchors, int B, int64_t n_anchors, int num_base_anchors, int fused_layout,
+                              float score_thr, float iou_thr, int max_det,
+                              float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
+                              int32_t* anchor_index, int32_t* counts,
+                              void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (B < 0 || n_anchors <= 0 || max_det <= 0 || max_det > 128 || num_base_anchors <= 0) return GPP_ERR_BAD_ARG;
+    if (n_anchors >= (1LL << 31) || n_anchors % num_base_anchors != 0) return GPP_ERR_UNSUPPORTED;
+    if (B == 0) return GPP_OK;
+    if (!cls_logits || !regression || !regression_dim || !anchors || !boxes || !dims || !scores || !labels ||
+        !orientations || !workspace)
+        return GPP_ERR_BAD_ARG;
+    if (((uintptr_t)cls_logits | (uintptr_t)anchors | (uintptr_t)workspace) & 15) return GPP_ERR_ALIGN;
+    size_t need = 0;
+    gpp_detect_workspace_bytes(B, n_anchors, &need);
+    if (workspace_bytes < need) return GPP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    int32_t* cnt = (int32_t*)ws;                                  // first 256 bytes: per-image counters
+    if (B > 64) return GPP_ERR_UNSUPPORTED;
+    const int64_t kstride = pow2_ceil(n_anchors);
+    unsigned long long* keys = (unsigned long long*)(ws + 256);
+    float4* wboxes = (float4*)(ws + 256 + (size_t)B * kstride * 8);
+    unsigned char* alive = (unsigned char*)(wboxes + (size_t)B * n_anchors);
+    hipError_t e = hipMemsetAsync(cnt, 0, 256, st);
+    if (e != hipSuccess) return (int)e;
+    candidates_kernel<<<dim3((unsigned)((n_anchors + 255) / 256), (unsigned)B), 256, 0, st>>>(
+        cls_logits, n_anchors, kstride, score_thr, keys, cnt);
+    static bool configured = false;
+    if (!configured) {
+        e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsKeys * 8);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    Layout L = {fused_layout, num_base_anchors};
+    nms_kernel<<<dim3((unsigned)B), kNmsThreads, kLdsKeys * 8, st>>>(
+        keys, cnt, kstride, cls_logits, regression, regression_dim, (const float4*)anchors, n_anchors, L, iou_thr, max_det,
+        boxes, dims, scores, labels, orientations, anchor_index, wboxes, alive);
+    if (counts) {
+        e = hipMemcpyAsync(counts, cnt, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}

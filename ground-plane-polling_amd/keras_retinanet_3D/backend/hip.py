@@ -73,6 +73,17 @@ def _declare(lib):
         [c_void_p, c_size_t, c_void_p]
     lib.gpp_conv2d_igemm.restype = c_int
     lib.gpp_conv2d_igemm.argtypes = [ctypes.POINTER(ConvDesc), c_void_p]
+    lib.gpp_stem_conv7x7_bn_relu.restype = c_int
+    lib.gpp_stem_conv7x7_bn_relu.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.gpp_maxpool3x3s2_same.restype = c_int
+    lib.gpp_maxpool3x3s2_same.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.gpp_relu.restype = c_int
+    lib.gpp_relu.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_void_p]
+    lib.gpp_detect_workspace_bytes.restype = c_int
+    lib.gpp_detect_workspace_bytes.argtypes = [c_int, c_int64, ctypes.POINTER(c_size_t)]
+    lib.gpp_detect_f32.restype = c_int
+    lib.gpp_detect_f32.argtypes = [c_void_p] * 4 + [c_int, c_int64, c_int, c_int, c_float, c_float, c_int] + \
+        [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]
     lib.gpp_conv2d_flops.restype = c_int
     lib.gpp_conv2d_flops.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_double)]
 

@@ -136,6 +136,50 @@ int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream);
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
 
+/* ------------------------------------------------------------------------------------------
+ * ResNet stem and small element-wise helpers.
+ * gpp_stem_conv7x7_bn_relu replaces keras_resnet's ZeroPadding2D(3) + conv1 (7x7, stride 2,
+ * no bias) + bn_conv1 (frozen, eps 1e-5) + ReLU (instantiated at models/resnet.py:88-93):
+ *   in (B, H, W, 3) float32 BGR mean-subtracted (utils/image.py:36-62), weight [7*7*3][64]
+ *   float32 = Keras HWIO kernel with the BN scale folded in, bias [64] = folded BN shift,
+ *   out (B, Ho, Wo, 64) of `dtype`, Ho = (H + 6 - 7)/2 + 1.
+ * gpp_maxpool3x3s2_same replaces MaxPooling2D(3x3, stride 2, padding 'same') 'pool1'.
+ * gpp_relu replaces Activation('relu') 'C6_relu' (models/retinanet.py:202).
+ * ---------------------------------------------------------------------------------------- */
+int gpp_stem_conv7x7_bn_relu(const float* in, const float* weight, const float* bias, void* out, int dtype,
+                             int B, int H, int W, void* stream);
+int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B, int H, int W, int C, void* stream);
+int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Detection decode: sigmoid, orientation fold, score threshold, NMS, top-k, box / dimension
+ * decode, -1 padding.  Replaces models/retinanet.py:72-73 (sigmoid), layers/_misc.py:133-141
+ * + backend/common.py:43-81 (RegressBoxes), layers/_misc.py:186-187 + backend/common.py:23-40
+ * (RegressDims) and layers/filter_detections.py:18-189 on its default path (nms=True,
+ * class_specific_filter=True, orientation_specific_filter=False, one class).
+ *
+ *   cls_logits     (B, n_anchors, 8)  f32  pre-sigmoid classification head output
+ *   regression     fused_layout == 0: (B, n_anchors, 12) f32 as the reference concatenates it
+ *                  (retinanet.py:112-124); fused_layout == 1: (B, n_anchors/A, 12*A) f32, per
+ *                  pixel [op1: 4A | op2: 2A | op3: 2A | op4: 2A | op5: 2A] (one fused conv)
+ *   regression_dim (B, n_anchors, 3)  f32
+ *   anchors        (n_anchors, 4)     f32  x1 y1 x2 y2 (layers/_misc.py:24-87), 16-byte aligned
+ *   boxes (B, max_det, 12) dims (B, max_det, 3) scores (B, max_det) f32,
+ *   labels / orientations (B, max_det) i32; rows past the survivors are -1
+ *   anchor_index   (B, max_det) i32 anchor id of each detection (may be NULL; not a reference output)
+ *   counts         (B) i32 number of anchors above score_thr per image (may be NULL)
+ *   workspace      gpp_detect_workspace_bytes() bytes, 16-byte aligned
+ * Reference constants: score_thr 0.05, iou_thr 0.5, max_det 100 (filter_detections.py:26-28).
+ * ---------------------------------------------------------------------------------------- */
+int gpp_detect_workspace_bytes(int B, int64_t n_anchors, size_t* bytes);
+
+int gpp_detect_f32(const float* cls_logits, const float* regression, const float* regression_dim,
+                   const float* anchors, int B, int64_t n_anchors, int num_base_anchors, int fused_layout,
+                   float score_thr, float iou_thr, int max_det,
+                   float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
+                   int32_t* anchor_index, int32_t* counts,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

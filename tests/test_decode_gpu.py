@@ -1,0 +1,83 @@
+"""
+GPU parity of the HIP decode / NMS kernels (C ABI gpp_detect_f32) against the golden vectors from
+the reference's layers and against the CPU oracle: bit-exact (integer + float32 op-by-op work).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import decode_np
+from keras_retinanet_3D.layers.filter_detections import filter_detections
+from keras_retinanet_3D.utils import anchors as A
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[len('decode_'):-4] for p in glob.glob(os.path.join(helpers.GOLDEN, 'decode_*.npz')))
+
+
+def to_fused(regression, n_base=12):
+    """ reference layout (B, A, 12) -> fused conv layout (B, P, [4A | 2A | 2A | 2A | 2A]) """
+    B, n, _ = regression.shape
+    r = regression.reshape(B, n // n_base, n_base, 12)
+    parts = [r[..., 0:4].reshape(B, -1, 4 * n_base)] + [r[..., 4 + 2 * k:6 + 2 * k].reshape(B, -1, 2 * n_base) for k in range(4)]
+    return np.ascontiguousarray(np.concatenate(parts, axis=2))
+
+
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('name', CASES)
+def test_hip_decode_matches_reference_goldens(name, fused):
+    g = dict(np.load(os.path.join(helpers.GOLDEN, 'decode_{}.npz'.format(name))))
+    reg = to_fused(g['regression']) if fused else g['regression']
+    out = filter_detections(g['logits'], reg, g['regression_dim'], g['anchors'], fused_regression=fused)
+    for got, key in zip(out[:5], ('boxes', 'dimensions', 'scores', 'labels', 'orientations')):
+        assert got.dtype == g[key].dtype and helpers.bits_equal(got, g[key]), key
+    cand = (np.maximum(g['classification'][..., :4], g['classification'][..., 4:]).max(-1) > np.float32(0.05)).sum(axis=1)
+    assert np.array_equal(out[6], cand.astype(np.int32))
+
+
+@pytest.mark.parametrize('hw,batch,mean,std', [((96, 160), 3, -3.5, 1.0), ((128, 416), 2, -4.6, 0.8), ((402, 1333), 1, -4.6, 0.75)])
+def test_hip_decode_random_against_oracle(hw, batch, mean, std):
+    rng = np.random.default_rng(hw[0] + batch)
+    anchors = A.anchors_for_image(hw)
+    n = anchors.shape[0]
+    logits = rng.normal(mean, std, size=(batch, n, 8)).astype(np.float32)
+    reg = rng.normal(0, 1, size=(batch, n, 12)).astype(np.float32)
+    dim = rng.normal(0, 1, size=(batch, n, 3)).astype(np.float32)
+    ref, ref_idx = decode_np.detect(logits, reg, dim, anchors)
+    out = filter_detections(logits, to_fused(reg), dim, anchors, fused_regression=True)
+    for got, want in zip(out[:5], ref):
+        assert helpers.bits_equal(got, want)
+    assert np.array_equal(out[5].astype(np.int64), ref_idx)
+
+
+def test_hip_decode_more_candidates_than_the_lds_sort_holds():
+    """ > 8192 candidates in one image takes the global-memory sort path """
+    rng = np.random.default_rng(9)
+    anchors = A.anchors_for_image((160, 256))
+    n = anchors.shape[0]
+    logits = rng.normal(-1.0, 1.0, size=(2, n, 8)).astype(np.float32)
+    logits[1] -= 8.0                                          # second image: nothing
+    reg = rng.normal(0, 1, size=(2, n, 12)).astype(np.float32)
+    dim = rng.normal(0, 1, size=(2, n, 3)).astype(np.float32)
+    ref, ref_idx = decode_np.detect(logits, reg, dim, anchors)
+    out = filter_detections(logits, reg, dim, anchors)
+    assert out[6][0] > 8192 and out[6][1] == 0
+    for got, want in zip(out[:5], ref):
+        assert helpers.bits_equal(got, want)
+
+
+def test_hip_decode_score_ties_break_by_anchor_index():
+    anchors = A.anchors_for_image((64, 64))
+    n = anchors.shape[0]
+    logits = np.full((1, n, 8), -9.0, np.float32)
+    logits[0, 5::97, 2] = 1.25                                 # many identical scores
+    reg = np.zeros((1, n, 12), np.float32)
+    dim = np.zeros((1, n, 3), np.float32)
+    ref, ref_idx = decode_np.detect(logits, reg, dim, anchors)
+    out = filter_detections(logits, reg, dim, anchors)
+    assert np.array_equal(out[5].astype(np.int64), ref_idx)
+    for got, want in zip(out[:5], ref):
+        assert helpers.bits_equal(got, want)

@@ -1,0 +1,51 @@
+""" GPU numerics of the stem (7x7 s2 conv + folded BN + ReLU), the 'same' max-pool and ReLU
+against plain PyTorch float32 references on the CPU. """
+import pytest
+import torch
+import torch.nn.functional as F
+
+from keras_retinanet_3D.backend import hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('dtype,tdt,eps', [(hip.GPP_BF16, torch.bfloat16, 2.0 ** -8), (hip.GPP_F16, torch.float16, 2.0 ** -10)])
+@pytest.mark.parametrize('B,H,W', [(2, 37, 53), (1, 64, 131), (1, 402, 1333)])
+def test_stem_matches_torch(B, H, W, dtype, tdt, eps):
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.rand((B, H, W, 3), generator=g) * 255.0 - 120.0
+    k = torch.randn((7, 7, 3, 64), generator=g) * 0.05
+    bias = torch.randn((64,), generator=g)
+    ref = torch.relu(F.conv2d(F.pad(x.permute(0, 3, 1, 2), (3, 3, 3, 3)), k.permute(3, 2, 0, 1), bias, stride=2)).permute(0, 2, 3, 1)
+    Ho, Wo = ref.shape[1:3]
+    dev = torch.device('cuda')
+    out = torch.full((B, Ho, Wo, 64), float('nan'), dtype=tdt, device=dev)
+    xd, kd, bd = x.to(dev).contiguous(), k.reshape(147, 64).to(dev).contiguous(), bias.to(dev)
+    hip.check(hip.lib().gpp_stem_conv7x7_bn_relu(hip.ptr(xd), hip.ptr(kd), hip.ptr(bd), hip.ptr(out), dtype, B, H, W, hip.stream_ptr()))
+    got = out.float().cpu()
+    err = (got - ref).abs()
+    assert bool((err <= eps * ref.abs() + 2e-3).all()), err.max().item()
+
+
+@pytest.mark.parametrize('B,H,W,C', [(2, 19, 27, 64), (1, 20, 28, 64), (1, 201, 667, 64)])
+def test_maxpool_matches_torch(B, H, W, C):
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn((B, H, W, C), generator=g).to(torch.bfloat16)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    pt = max((Ho - 1) * 2 + 3 - H, 0)
+    pl = max((Wo - 1) * 2 + 3 - W, 0)
+    xp = F.pad(x.float().permute(0, 3, 1, 2), (pl // 2, pl - pl // 2, pt // 2, pt - pt // 2), value=float('-inf'))
+    ref = F.max_pool2d(xp, 3, 2).permute(0, 2, 3, 1)
+    dev = torch.device('cuda')
+    out = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=dev)
+    xd = x.to(dev).contiguous()
+    hip.check(hip.lib().gpp_maxpool3x3s2_same(hip.ptr(xd), hip.ptr(out), hip.GPP_BF16, B, H, W, C, hip.stream_ptr()))
+    assert torch.equal(out.float().cpu(), ref)
+
+
+def test_relu():
+    dev = torch.device('cuda')
+    x = torch.randn((3, 7, 21, 512)).to(torch.bfloat16).to(dev)
+    out = torch.empty_like(x)
+    hip.check(hip.lib().gpp_relu(hip.ptr(x), hip.ptr(out), hip.GPP_BF16, x.numel(), hip.stream_ptr()))
+    assert torch.equal(out, torch.relu(x))

@@ -1,0 +1,59 @@
+""" Micro-benchmark of gpp_conv2d_igemm on the shapes that dominate the network. """
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'ground-plane-polling_amd'))
+
+import torch  # noqa: E402
+from keras_retinanet_3D.layers import conv as C  # noqa: E402
+
+PYR = [(51, 167), (26, 84), (13, 42), (7, 21), (4, 11)]
+
+
+def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False):
+    dev = torch.device('cuda')
+    tdt = C.torch_dtype(dtype)
+    total = sum(h * w for h, w in shapes)
+    x = (torch.randn((B, total, Cin), device=dev) * 0.5).to(tdt)
+    o = torch.empty((B, total, Cout), device=dev, dtype=torch.float32 if out_f32 else tdt)
+    w = C.pack_weight((torch.randn((K, K, Cin, Cout)) * 0.02).numpy(), dtype, dev)
+    bias = torch.zeros((Cout,), device=dev)
+    ins, outs, off = [], [], 0
+    for h, wd in shapes:
+        ins.append(C.FMap(x, B, h, wd, Cin, off=off * Cin, bstride=total * Cin))
+        outs.append(C.FMap(o, B, h, wd, Cout, off=off * Cout, bstride=total * Cout))
+        off += h * wd
+    d = C.conv_desc(ins, outs, w, bias, K, K, Cin, Cout, pad=(K // 2, K // 2), relu=True, dtype=dtype, out_f32=out_f32)
+    for _ in range(3):
+        C.run_conv(d)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        C.run_conv(d)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = C.conv_flops(d)
+    print('{:28s} {:8.3f} ms  {:8.1f} TFLOP/s  ({:.1f} GFLOP)'.format(name, ms, fl / ms / 1e9, fl / 1e9))
+    return ms
+
+
+if __name__ == '__main__':
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    bench('reg tower 3x3 512->512', B, PYR, 512, 512, 3)
+    bench('cls tower 3x3 256->256', B, PYR, 256, 256, 3)
+    bench('dim tower 3x3 128->128', B, PYR, 128, 128, 3)
+    bench('reg out 3x3 512->144 f32', B, PYR, 512, 144, 3, out_f32=True)
+    bench('P3 3x3 512->512', B, PYR[:1], 512, 512, 3)
+    bench('res2 1x1 256->64', B, [(101, 334)], 256, 64, 1)
+    bench('res2 3x3 64->64', B, [(101, 334)], 64, 64, 3)
+    bench('res2 1x1 64->256', B, [(101, 334)], 64, 256, 1)
+    bench('res3 3x3 128->128', B, [(51, 167)], 128, 128, 3)
+    bench('res4 3x3 256->256', B, [(26, 84)], 256, 256, 3)
+    bench('res4 1x1 1024->256', B, [(26, 84)], 1024, 256, 1)
+    bench('res5 3x3 512->512', B, [(13, 42)], 512, 512, 3)
+    bench('res5 1x1 512->2048', B, [(13, 42)], 512, 2048, 1)
+    bench('f16 reg tower 3x3', B, PYR, 512, 512, 3, dtype='f16')
