@@ -1,0 +1,92 @@
+// Plan runner: enqueue a whole predict_on_batch from a host array of descriptors (include/gpp.h).
+// Stateless; every op forwards to the typed C-ABI entry point, so a plan run is exactly the same
+// launches as calling those entry points one by one from the host language.
+#include <hip/hip_runtime.h>
+
+#include "gpp.h"
+
+extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, void* const* events, int n_events)
+{
+    if (!ops || n_ops < 0) return GPP_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int ev = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        const gpp_plan_op& op = ops[i];
+        if (!op.desc) return GPP_ERR_BAD_ARG;
+        const bool timed = op.tag != 0 && events && ev + 1 < n_events;
+        if (timed) {
+            hipError_t e = hipEventRecord((hipEvent_t)events[ev], st);
+            if (e != hipSuccess) return (int)e;
+        }
+        int rc = GPP_ERR_UNSUPPORTED;
+        switch (op.kind) {
+        case GPP_OP_STEM: {
+            const gpp_stem_desc* d = (const gpp_stem_desc*)op.desc;
+            rc = gpp_stem_conv7x7_bn_relu(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
+            break;
+        }
+        case GPP_OP_MAXPOOL: {
+            const gpp_pool_desc* d = (const gpp_pool_desc*)op.desc;
+            rc = gpp_maxpool3x3s2_same(d->in, d->out, d->dtype, d->B, d->H, d->W, d->C, stream);
+            break;
+        }
+        case GPP_OP_CONV:
+            rc = gpp_conv2d_igemm((const gpp_conv_desc*)op.desc, stream);
+            break;
+        case GPP_OP_RELU: {
+            const gpp_relu_desc* d = (const gpp_relu_desc*)op.desc;
+            rc = gpp_relu_strided(d->in, d->in_bstride, d->out, d->out_bstride, d->dtype, d->B, d->count, stream);
+            break;
+        }
+        case GPP_OP_DETECT: {
+            const gpp_detect_desc* d = (const gpp_detect_desc*)op.desc;
+            rc = gpp_detect_f32(d->cls_logits, d->regression, d->regression_dim, d->anchors, d->B, d->n_anchors,
+                                d->num_base_anchors, d->fused_layout, d->score_thr, d->iou_thr, d->max_det, d->boxes, d->dims,
+                                d->scores, d->labels, d->orientations, d->anchor_index, d->counts, d->workspace,
+                                d->workspace_bytes, stream);
+            break;
+        }
+        case GPP_OP_POLL: {
+            const gpp_poll_desc* d = (const gpp_poll_desc*)op.desc;
+            rc = gpp_poll_f32(d->boxes, d->dims, d->orient, d->P_inv, d->planes, d->B, d->D, d->N, d->planes_batched, d->thr,
+                              d->keypoints, d->keyplanes, d->residuals, d->best_idx, d->workspace, d->workspace_bytes, stream);
+            break;
+        }
+        default:
+            return GPP_ERR_BAD_ARG;
+        }
+        if (rc != GPP_OK) return rc;
+        if (timed) {
+            hipError_t e = hipEventRecord((hipEvent_t)events[ev + 1], st);
+            if (e != hipSuccess) return (int)e;
+            ev += 2;
+        }
+    }
+    return GPP_OK;
+}
+
+extern "C" int gpp_event_create(void** event)
+{
+    if (!event) return GPP_ERR_BAD_ARG;
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return (int)rc;
+    *event = (void*)e;
+    return GPP_OK;
+}
+
+extern "C" int gpp_event_destroy(void* event)
+{
+    if (!event) return GPP_ERR_BAD_ARG;
+    hipError_t rc = hipEventDestroy((hipEvent_t)event);
+    return rc == hipSuccess ? GPP_OK : (int)rc;
+}
+
+extern "C" int gpp_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    if (!start || !stop || !ms) return GPP_ERR_BAD_ARG;
+    hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+    if (rc != hipSuccess) return (int)rc;
+    rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    return rc == hipSuccess ? GPP_OK : (int)rc;
+}

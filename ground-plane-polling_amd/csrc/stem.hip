@@ -113,13 +113,16 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const scalar* __restrict__
 }
 
 template <typename scalar, typename vec8>
-__global__ __launch_bounds__(256) void relu_kernel(const scalar* __restrict__ in, scalar* __restrict__ out, int64_t n8)
+__global__ __launch_bounds__(256) void relu_kernel(const scalar* __restrict__ in, int64_t in_bs, scalar* __restrict__ out,
+                                                   int64_t out_bs, int64_t n8)
 {
+    const scalar* src = in + (int64_t)blockIdx.y * in_bs;
+    scalar* dst = out + (int64_t)blockIdx.y * out_bs;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
-        vec8 v = *(const vec8*)(in + e * 8);
+        vec8 v = *(const vec8*)(src + e * 8);
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = (scalar)fmaxf((float)v[c], 0.0f);
-        *(vec8*)(out + e * 8) = v;
+        *(vec8*)(dst + e * 8) = v;
     }
 }
 
@@ -167,18 +170,25 @@ extern "C" int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B
     return result();
 }
 
-extern "C" int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream)
+extern "C" int gpp_relu_strided(const void* in, int64_t in_bstride, void* out, int64_t out_bstride, int dtype, int B,
+                                int64_t count, void* stream)
 {
-    if (!in || !out || count <= 0 || count % 8 != 0) return GPP_ERR_BAD_ARG;
+    if (!in || !out || B <= 0 || count <= 0 || count % 8 != 0 || in_bstride % 8 != 0 || out_bstride % 8 != 0)
+        return GPP_ERR_BAD_ARG;
     if (((uintptr_t)in | (uintptr_t)out) & 15) return GPP_ERR_ALIGN;
     const int64_t n8 = count / 8;
-    const unsigned blocks = (unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    const dim3 grid((unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GPP_BF16)
-        relu_kernel<__bf16, bf16x8><<<blocks, 256, 0, st>>>((const __bf16*)in, (__bf16*)out, n8);
+        relu_kernel<__bf16, bf16x8><<<grid, 256, 0, st>>>((const __bf16*)in, in_bstride, (__bf16*)out, out_bstride, n8);
     else if (dtype == GPP_F16)
-        relu_kernel<_Float16, f16x8><<<blocks, 256, 0, st>>>((const _Float16*)in, (_Float16*)out, n8);
+        relu_kernel<_Float16, f16x8><<<grid, 256, 0, st>>>((const _Float16*)in, in_bstride, (_Float16*)out, out_bstride, n8);
     else
         return GPP_ERR_UNSUPPORTED;
     return result();
+}
+
+extern "C" int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream)
+{
+    return gpp_relu_strided(in, 0, out, 0, dtype, 1, count, stream);
 }

@@ -1,1 +1,66 @@
+"""
+Model loading surface of the reference, kept name for name for the inference path
+(/root/reference/keras_retinanet_3D/models/__init__.py:9-88):
 
+    backbone(name)                       -> Backbone object (validate(), retinanet())
+    load_model(filepath, backbone_name)  -> object with predict_on_batch([images, P_inv, planes])
+
+`filepath` may be
+    'synthetic:<seed>'   seeded random weights of the exact architecture (no trained weights ship
+                         with the reference, README.md:75)
+    '<file>.npz'         weights saved by models.weights.save_weights (Keras layer names)
+    '<file>.h5'          a Keras inference/training model file (needs h5py)
+"""
+
+
+class Backbone(object):
+    """ This class stores additional information on backbones (reference models/__init__.py:9-39). """
+
+    def __init__(self, backbone):
+        self.backbone = backbone
+        self.custom_objects = {}      # Keras deserialisation table of the reference; nothing to register here
+        self.validate()
+
+    def retinanet(self, *args, **kwargs):
+        raise NotImplementedError('retinanet method not implemented.')
+
+    def download_imagenet(self):
+        raise NotImplementedError('download_imagenet method not implemented.')
+
+    def validate(self):
+        raise NotImplementedError('validate method not implemented.')
+
+
+def backbone(backbone_name):
+    """ Returns a backbone object for the given backbone (reference models/__init__.py:42-56). """
+    if 'resnet' in backbone_name:
+        from .resnet import ResNetBackbone as b
+    else:
+        raise NotImplementedError('Backbone class for  \'{}\' not implemented.'.format(backbone_name))
+    return b(backbone_name)
+
+
+def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, class_specific_filter=True,
+               orientation_specific_filter=False, dtype='bf16'):
+    """ Loads a RetinaNet-3D inference model (reference models/__init__.py:59-88).
+
+    `convert` is accepted for signature compatibility: every model this function returns already
+    contains the decode / NMS / ground-plane-polling stages (`retinanet_bbox`, retinanet.py:359-422).
+    `dtype` ('bf16' | 'f16') is the 16-bit storage type of activations and weights on the GPU.
+    """
+    from . import weights as W
+    from .retinanet import RetinaNet3D
+    b = backbone(backbone_name)
+    name = b.backbone.split('_')[0]
+    if isinstance(filepath, dict):
+        w = filepath
+    elif isinstance(filepath, str) and filepath.startswith('synthetic'):
+        seed = int(filepath.split(':', 1)[1]) if ':' in filepath else 1234
+        w = W.synthetic_weights(name, seed)
+    else:
+        w = W.load_weights(filepath)
+    model = RetinaNet3D(w, backbone_name=name, dtype=dtype, nms=nms, class_specific_filter=class_specific_filter,
+                        orientation_specific_filter=orientation_specific_filter)
+    if convert:
+        model.summary()
+    return model

@@ -1,0 +1,364 @@
+"""
+RetinaNet-3D inference model on MI355X: the object `models.load_model` returns.
+
+It plays the role of the keras.models.Model that the reference builds in
+/root/reference/keras_retinanet_3D/models/retinanet.py:359-422 (`retinanet_bbox`):
+    backbone (keras_resnet, models/resnet.py:88-102) -> C3, C4, C5
+    __create_pyramid_features :170-205                -> P3..P7 (512 channels)
+    regression / regression_dim / classification heads :24-167, applied per level, concatenated :257-281
+    Anchors + RegressBoxes + RegressDims :284-311, :411-412 ; FilterDetections :415 ; FitRoadPlanes :416
+with the same `predict_on_batch([images, P_inv, planes])` -> 8 arrays contract
+(bin/run_network.py:105-110; output order retinanet.py:418-419).
+
+Nothing is traced or compiled at run time: for a given (batch, H, W) the model lays out its
+activations in HBM once and records a *plan* -- a flat array of C-ABI descriptors (include/gpp.h) --
+that one `gpp_plan_run` call enqueues on the current HIP stream.  All arithmetic happens in the
+hand-written kernels of ../csrc; PyTorch only owns the device buffers.
+
+HBM layout
+  * activations NHWC, 16-bit (bf16 default), one dense buffer per live tensor
+  * the five pyramid levels of every FPN / head tensor are stored back to back per image,
+    (B, 11438, C) for a 402x1333 input, so that one grouped launch covers all levels and the head
+    outputs come out directly in the reference's concatenated (B, A, k) order
+  * head outputs (classification logits, fused 144-channel regression, dimensions) float32
+  * weights [C_out][KH*KW*C_in] 16-bit with the frozen BatchNormalization folded in, biases float32
+"""
+
+import ctypes
+
+import numpy as np
+
+from ..backend import hip
+from ..layers import conv as C
+from ..layers.filter_detections import MAX_DETECTIONS, NMS_THRESHOLD, SCORE_THRESHOLD
+from ..utils import anchors as anchor_utils
+from ..utils.gpp_utils import POLL_THRESHOLD
+from . import weights as W
+
+
+class StemDesc(ctypes.Structure):
+    _fields_ = [('inp', ctypes.c_void_p), ('weight', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('out', ctypes.c_void_p),
+                ('dtype', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32)]
+
+
+class PoolDesc(ctypes.Structure):
+    _fields_ = [('inp', ctypes.c_void_p), ('out', ctypes.c_void_p), ('dtype', ctypes.c_int32), ('B', ctypes.c_int32),
+                ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('C', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class ReluDesc(ctypes.Structure):
+    _fields_ = [('inp', ctypes.c_void_p), ('out', ctypes.c_void_p), ('in_bstride', ctypes.c_int64),
+                ('out_bstride', ctypes.c_int64), ('count', ctypes.c_int64), ('dtype', ctypes.c_int32), ('B', ctypes.c_int32)]
+
+
+class DetectDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ('cls_logits', 'regression', 'regression_dim', 'anchors', 'boxes', 'dims',
+                                               'scores', 'labels', 'orientations', 'anchor_index', 'counts', 'workspace')] + \
+               [('workspace_bytes', ctypes.c_size_t), ('n_anchors', ctypes.c_int64),
+                ('B', ctypes.c_int32), ('num_base_anchors', ctypes.c_int32), ('fused_layout', ctypes.c_int32),
+                ('max_det', ctypes.c_int32), ('score_thr', ctypes.c_float), ('iou_thr', ctypes.c_float)]
+
+
+class PollDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ('boxes', 'dims', 'orient', 'P_inv', 'planes', 'keypoints', 'keyplanes',
+                                               'residuals', 'best_idx', 'workspace')] + \
+               [('workspace_bytes', ctypes.c_size_t), ('B', ctypes.c_int32), ('D', ctypes.c_int32), ('N', ctypes.c_int32),
+                ('planes_batched', ctypes.c_int32), ('thr', ctypes.c_float), ('reserved', ctypes.c_int32)]
+
+
+class PlanOp(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('tag', ctypes.c_int32), ('desc', ctypes.c_void_p)]
+
+
+OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL = 1, 2, 3, 4, 5, 6
+
+
+class Plan(object):
+    """ Everything one (batch, H, W, N planes) configuration needs: buffers, descriptors, op array. """
+
+    def __init__(self):
+        self.keep = []          # ctypes descriptors and torch buffers kept alive
+        self.ops = []           # (kind, tag, desc, name, flops)
+        self.array = None
+        self.flops = 0.0
+
+    def add(self, kind, desc, name, tag=0, flops=0.0):
+        self.keep.append(desc)
+        self.ops.append((kind, tag, desc, name, flops))
+        self.flops += flops
+
+    def finalize(self):
+        arr = (PlanOp * len(self.ops))()
+        for i, (kind, tag, desc, _, _) in enumerate(self.ops):
+            arr[i].kind, arr[i].tag, arr[i].desc = kind, tag, ctypes.addressof(desc)
+        self.array = arr
+
+
+class RetinaNet3D(object):
+    """ Inference model: ResNet-50/101/152 + FPN + heads + decode + ground-plane polling. """
+
+    def __init__(self, weights, backbone_name='resnet50', dtype='bf16', nms=True, class_specific_filter=True,
+                 orientation_specific_filter=False, name='retinanet-bbox'):
+        import torch
+        if not nms or orientation_specific_filter:
+            raise NotImplementedError('the device decode implements nms=True, orientation_specific_filter=False '
+                                      '(what models.load_model produces by default)')
+        self.name = name
+        self.backbone_name = backbone_name.split('_')[0]
+        if self.backbone_name not in W.BLOCKS:
+            raise ValueError('Backbone (\'{}\') not in allowed backbones ({}).'.format(backbone_name, sorted(W.BLOCKS)))
+        self.dtype = dtype
+        self.tdtype = C.torch_dtype(dtype)
+        self.device = hip.require_device()
+        hip.lib()
+        self.torch = torch
+        self._plans = {}
+        self._anchors = {}
+        self._upload(weights)
+        self.tag_names = []          # filled by the plan builder: names of event-tagged ops
+
+    # ------------------------------------------------------------------ weights
+    def _upload(self, weights):
+        torch, dev = self.torch, self.device
+        self.conv_w = {}
+
+        def put(name, kernel, bias):
+            self.conv_w[name] = (C.pack_weight(kernel, self.dtype, dev), torch.as_tensor(bias).to(dev).contiguous(),
+                                 kernel.shape)
+
+        for conv, bn, kh, kw, cin, cout, _ in W.backbone_layers(self.backbone_name):
+            k, b = W.folded_conv(weights, conv, bn)
+            if k.shape != (kh, kw, cin, cout):
+                raise ValueError('weight {} has shape {}, expected {}'.format(conv, k.shape, (kh, kw, cin, cout)))
+            if conv == 'conv1':
+                self.stem_w = torch.as_tensor(k.reshape(147, 64)).to(dev).contiguous()
+                self.stem_b = torch.as_tensor(b).to(dev).contiguous()
+            else:
+                put(conv, k, b)
+        for name, k_, cin, cout, _ in W.fpn_layers():
+            k, b = W.folded_conv(weights, name)
+            put(name, k, b)
+        for name, cin, cout, kind in W.head_layers():
+            if name.startswith('pyramid_regression_op'):
+                continue
+            k, b = W.folded_conv(weights, name)
+            put(name, k, b)
+        k, b = W.fused_regression_outputs(weights)
+        put('pyramid_regression_ops', k, b)
+
+    # ------------------------------------------------------------------ plan
+    def _anchor_table(self, hw):
+        if hw not in self._anchors:
+            self._anchors[hw] = self.torch.as_tensor(anchor_utils.anchors_for_image(hw)).to(self.device).contiguous()
+        return self._anchors[hw]
+
+    def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0):
+        wt, bias, shape = self.conv_w[name]
+        kh, kw, cin, cout = shape
+        if pad is None:
+            pad = (0, 0)
+        d = C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
+                        residuals=residuals, dtype=self.dtype, out_f32=out_f32)
+        plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d))
+
+    def _build(self, B, H, Wd, n_planes, planes_batched):
+        torch, dev, dt = self.torch, self.device, self.tdtype
+        plan = Plan()
+        plan.shape = (B, H, Wd, n_planes, planes_batched)
+
+        def fmap(h, w, c, dtype=None):
+            f = C.FMap.empty(B, h, w, c, dtype or dt, dev)
+            plan.keep.append(f.buf)
+            return f
+
+        # ---- inputs
+        plan.images = torch.empty((B, H, Wd, 3), dtype=torch.float32, device=dev)
+        plan.P_inv = torch.empty((B, 4, 3), dtype=torch.float32, device=dev)
+        plan.planes = torch.empty((B, n_planes, 4) if planes_batched else (n_planes, 4), dtype=torch.float32, device=dev)
+
+        # ---- stem: conv1 + bn_conv1 + relu, pool1
+        H1, W1 = (H + 6 - 7) // 2 + 1, (Wd + 6 - 7) // 2 + 1
+        stem = fmap(H1, W1, 64)
+        d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
+                     C.gpp_dtype(self.dtype), B, H, Wd)
+        plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
+        H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
+        x = fmap(H2, W2, 64)
+        plan.add(OP_MAXPOOL, PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_dtype(self.dtype), B, H1, W1, 64, 0), 'pool1')
+
+        # ---- bottleneck stages (keras_resnet bottleneck_2d: stride on the first 1x1)
+        feats = []
+        for stage, n_blocks in enumerate(W.BLOCKS[self.backbone_name]):
+            f = 64 * 2 ** stage
+            for block in range(n_blocks):
+                nm = W.block_name(self.backbone_name, stage, block)
+                stride = 2 if (block == 0 and stage > 0) else 1
+                ho, wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
+                a = fmap(ho, wo, f)
+                self._conv(plan, 'res{}_branch2a'.format(nm), [x], [a], 1, stride=stride, relu=True)
+                bmap = fmap(ho, wo, f)
+                self._conv(plan, 'res{}_branch2b'.format(nm), [a], [bmap], 3, pad=(1, 1), relu=True)
+                if block == 0:
+                    sc = fmap(ho, wo, 4 * f)
+                    self._conv(plan, 'res{}_branch1'.format(nm), [x], [sc], 1, stride=stride)
+                else:
+                    sc = x
+                y = fmap(ho, wo, 4 * f)
+                self._conv(plan, 'res{}_branch2c'.format(nm), [bmap], [y], 1, relu=True, residuals=[sc])
+                x = y
+            feats.append(x)
+        _, C3, C4, C5 = feats
+
+        # ---- FPN into one pyramid tensor (B, sum(H_l*W_l), 512)
+        shapes = anchor_utils.pyramid_shapes((H, Wd))
+        if (C3.H, C3.W) != shapes[0] or (C4.H, C4.W) != shapes[1] or (C5.H, C5.W) != shapes[2]:
+            raise RuntimeError('backbone / pyramid shape mismatch: {} vs {}'.format([(C3.H, C3.W), (C4.H, C4.W), (C5.H, C5.W)], shapes))
+        pix = [h * w for h, w in shapes]
+        total = sum(pix)
+        lvl_off = [sum(pix[:i]) for i in range(5)]
+        plan.n_anchors = total * anchor_utils.NUM_BASE_ANCHORS
+
+        def pyramid(c, dtype=None):
+            buf = torch.empty((B, total, c), dtype=dtype or dt, device=dev)
+            plan.keep.append(buf)
+            return buf, [C.FMap(buf, B, shapes[i][0], shapes[i][1], c, off=lvl_off[i] * c, bstride=total * c) for i in range(5)]
+
+        pyr, P = pyramid(512)
+        T5 = fmap(C5.H, C5.W, 512)
+        self._conv(plan, 'C5_reduced', [C5], [T5], 1)
+        self._conv(plan, 'P5', [T5], [P[2]], 3, pad=(1, 1))
+        T4 = fmap(C4.H, C4.W, 512)
+        self._conv(plan, 'C4_reduced', [C4], [T4], 1, residuals=[T5])          # + UpsampleLike(P5, C4), fused
+        self._conv(plan, 'P4', [T4], [P[1]], 3, pad=(1, 1))
+        T3 = fmap(C3.H, C3.W, 512)
+        self._conv(plan, 'C3_reduced', [C3], [T3], 1, residuals=[T4])          # + UpsampleLike(P4, C3), fused
+        self._conv(plan, 'P3', [T3], [P[0]], 3, pad=(1, 1))
+        self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]))
+        R6 = fmap(shapes[3][0], shapes[3][1], 512)
+        plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * 2, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
+                                   pix[3] * 512, C.gpp_dtype(self.dtype), B), 'C6_relu')
+        self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
+                   pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]))
+
+        # ---- heads: every layer is one grouped launch over the five levels
+        def tower(prefix, width, tag=0):
+            src = P
+            for i in range(4):
+                _, dst = pyramid(width)
+                self._conv(plan, '{}_{}'.format(prefix, i), src, dst, 3, pad=(1, 1), relu=True, tag=tag)
+                src = dst
+            return src
+
+        reg_t = tower('pyramid_regression', 512, tag=1)
+        plan.regression, reg_o = pyramid(144, torch.float32)
+        self._conv(plan, 'pyramid_regression_ops', reg_t, reg_o, 3, pad=(1, 1), out_f32=True)
+        dim_t = tower('pyramid_regression_dim', 128)
+        plan.regression_dim, dim_o = pyramid(36, torch.float32)
+        self._conv(plan, 'pyramid_regression_dim', dim_t, dim_o, 3, pad=(1, 1), out_f32=True)
+        cls_t = tower('pyramid_classification', 256)
+        plan.cls_logits, cls_o = pyramid(96, torch.float32)
+        self._conv(plan, 'pyramid_classification', cls_t, cls_o, 3, pad=(1, 1), out_f32=True)
+
+        # ---- decode + NMS (RegressBoxes, RegressDims, FilterDetections)
+        D = MAX_DETECTIONS
+        f32, i32 = torch.float32, torch.int32
+        plan.boxes = torch.empty((B, D, 12), dtype=f32, device=dev)
+        plan.dimensions = torch.empty((B, D, 3), dtype=f32, device=dev)
+        plan.scores = torch.empty((B, D), dtype=f32, device=dev)
+        plan.labels = torch.empty((B, D), dtype=i32, device=dev)
+        plan.orientations = torch.empty((B, D), dtype=i32, device=dev)
+        plan.anchor_index = torch.empty((B, D), dtype=i32, device=dev)
+        plan.counts = torch.zeros((B,), dtype=i32, device=dev)
+        need = hip.c_size_t(0)
+        hip.check(hip.lib().gpp_detect_workspace_bytes(B, plan.n_anchors, need), 'gpp_detect_workspace_bytes')
+        plan.detect_ws = torch.empty((int(need.value),), dtype=torch.uint8, device=dev)
+        anchors = self._anchor_table((H, Wd))
+        dd = DetectDesc(plan.cls_logits.data_ptr(), plan.regression.data_ptr(), plan.regression_dim.data_ptr(),
+                        anchors.data_ptr(), plan.boxes.data_ptr(), plan.dimensions.data_ptr(), plan.scores.data_ptr(),
+                        plan.labels.data_ptr(), plan.orientations.data_ptr(), plan.anchor_index.data_ptr(),
+                        plan.counts.data_ptr(), plan.detect_ws.data_ptr(), plan.detect_ws.numel(), plan.n_anchors,
+                        B, anchor_utils.NUM_BASE_ANCHORS, 1, D, SCORE_THRESHOLD, NMS_THRESHOLD)
+        plan.add(OP_DETECT, dd, 'filtered_detections')
+
+        # ---- ground-plane polling (FitRoadPlanes)
+        plan.keypoints = torch.empty((B, D, 4, 3), dtype=f32, device=dev)
+        plan.keyplanes = torch.empty((B, D, 1, 4), dtype=f32, device=dev)
+        plan.residuals = torch.empty((B, D), dtype=f32, device=dev)
+        plan.best_index = torch.empty((B, D), dtype=i32, device=dev)
+        hip.check(hip.lib().gpp_poll_workspace_bytes(B, n_planes, int(planes_batched), need), 'gpp_poll_workspace_bytes')
+        plan.poll_ws = torch.empty((max(int(need.value), 16),), dtype=torch.uint8, device=dev)
+        pd = PollDesc(plan.boxes.data_ptr(), plan.dimensions.data_ptr(), plan.orientations.data_ptr(), plan.P_inv.data_ptr(),
+                      plan.planes.data_ptr(), plan.keypoints.data_ptr(), plan.keyplanes.data_ptr(), plan.residuals.data_ptr(),
+                      plan.best_index.data_ptr(), plan.poll_ws.data_ptr(), plan.poll_ws.numel(), B, D, n_planes,
+                      int(planes_batched), POLL_THRESHOLD, 0)
+        plan.add(OP_POLL, pd, 'fit_road_planes', flops=162.0 * B * D * n_planes)
+        plan.finalize()
+        plan.tagged = [name for _, tag, _, name, _ in plan.ops if tag]
+        return plan
+
+    def plan_for(self, B, H, Wd, n_planes, planes_batched):
+        key = (int(B), int(H), int(Wd), int(n_planes), bool(planes_batched))
+        if key not in self._plans:
+            self._plans[key] = self._build(*key)
+        return self._plans[key]
+
+    # ------------------------------------------------------------------ execution
+    def run_plan(self, plan, events=None):
+        """ Enqueue the whole forward on the current stream (asynchronous). """
+        if events is not None:
+            arr = (ctypes.c_void_p * len(events))(*events)
+            rc = hip.lib().gpp_plan_run(plan.array, len(plan.ops), hip.stream_ptr(), arr, len(events))
+        else:
+            rc = hip.lib().gpp_plan_run(plan.array, len(plan.ops), hip.stream_ptr(), None, 0)
+        hip.check(rc, 'gpp_plan_run')
+
+    def outputs(self, plan):
+        """ the 8 device tensors in the reference's output order (retinanet.py:418-419) """
+        return [plan.boxes, plan.dimensions, plan.scores, plan.labels, plan.orientations,
+                plan.keypoints, plan.keyplanes, plan.residuals]
+
+    def predict_on_batch(self, inputs):
+        """ inputs = [images (B, H, W, 3) float32 BGR mean-subtracted, P_inv (B, 4, 3), planes (B, N, 4)]
+        (NumPy, as bin/run_network.py:105 builds them, or torch tensors already on the device).
+        Returns the list of 8 writable NumPy arrays of the reference:
+        boxes (B,100,12) f32, dimensions (B,100,3) f32, scores (B,100) f32, labels (B,100) i32,
+        orientations (B,100) i32, keypoints (B,100,4,3) f32, keyplanes (B,100,1,4) f32, residuals (B,100) f32. """
+        plan = self.stage_inputs(inputs)
+        self.run_plan(plan)
+        return [t.cpu().numpy() for t in self.outputs(plan)]
+
+    def stage_inputs(self, inputs):
+        """ Copy [images, P_inv, planes] into the plan's device buffers; returns the plan. """
+        torch = self.torch
+        if not isinstance(inputs, (list, tuple)) or len(inputs) != 3:
+            raise ValueError('predict_on_batch expects [images, P_inv, planes]')
+        images, P_inv, planes = inputs
+        shp = tuple(images.shape)
+        if len(shp) != 4 or shp[3] != 3:
+            raise ValueError('images must be (B, H, W, 3), got {}'.format(shp))
+        if tuple(P_inv.shape) != (shp[0], 4, 3):
+            raise ValueError('P_inv must be (B, 4, 3), got {}'.format(tuple(P_inv.shape)))
+        pshape = tuple(planes.shape)
+        batched = len(pshape) == 3
+        if not ((batched and pshape[0] == shp[0] and pshape[2] == 4) or (len(pshape) == 2 and pshape[1] == 4)) or pshape[-2] < 1:
+            raise ValueError('planes must be (B, N, 4) or (N, 4), got {}'.format(pshape))
+        plan = self.plan_for(shp[0], shp[1], shp[2], pshape[-2], batched)
+
+        def put(dst, src):
+            if isinstance(src, torch.Tensor):
+                dst.copy_(src.to(dtype=dst.dtype), non_blocking=True)
+            else:
+                dst.copy_(torch.as_tensor(np.ascontiguousarray(src, dtype=np.float32)), non_blocking=True)
+
+        put(plan.images, images)
+        put(plan.P_inv, P_inv)
+        put(plan.planes, planes)
+        return plan
+
+    # Keras-style conveniences used by the reference's scripts
+    def predict(self, inputs, batch_size=None, verbose=0):
+        return self.predict_on_batch(inputs)
+
+    def summary(self):
+        print('{}: {} + FPN + heads, {} storage, {} conv launches'.format(
+            self.name, self.backbone_name, self.dtype, len(self.conv_w)))

@@ -1,0 +1,176 @@
+"""
+Weights of the RetinaNet-3D graph: layer inventory, synthetic (seeded) initialisation, files,
+and folding of the frozen BatchNormalization layers into the preceding convolutions.
+
+The layer names are the Keras names of the reference graph, so that a converted `.h5`
+(reference bin/convert_model.py:43-53) maps one to one onto this container:
+    FPN     C5_reduced P5 C4_reduced P4 C3_reduced P3 P6 P7          models/retinanet.py:183-203
+    heads   pyramid_regression_{0..3}, pyramid_regression_op{1..5}   models/retinanet.py:100-120
+            pyramid_regression_dim_{0..3}, pyramid_regression_dim    models/retinanet.py:151-161
+            pyramid_classification_{0..3}, pyramid_classification    models/retinanet.py:52-69
+    backbone (third-party keras_resnet, models/resnet.py:88-93): conv1 / bn_conv1,
+            res{S}{B}_branch{2a,2b,2c,1} / bn{S}{B}_branch{...}; block letters a, b, c ... except
+            stages 3 and 4 of ResNet-101/152 which use a, b1, b2, ... (keras_resnet numerical names)
+
+Arrays are stored in Keras conventions: conv kernels HWIO float32 '<layer>/kernel', biases
+'<layer>/bias', BatchNormalization '<bn>/gamma', '/beta', '/moving_mean', '/moving_variance'.
+
+No trained weights ship with the reference (README.md:75 is a link), so benchmarks and tests use
+`synthetic:<seed>` weights: the architecture is exact, the values are random but scaled so that
+activations stay O(1) through the 50-152 layers and the number of anchors above the 0.05 score
+threshold is realistic (about a thousand per 402x1333 image).
+"""
+
+import zlib
+
+import numpy as np
+
+BN_EPSILON = 1e-5                     # keras_resnet BatchNormalization(epsilon=1e-5)
+NUM_ANCHORS = 12                      # models/retinanet.py:230-235: 3 ratios x 4 scales
+BLOCKS = {'resnet50': (3, 4, 6, 3), 'resnet101': (3, 4, 23, 3), 'resnet152': (3, 8, 36, 3)}
+NUMERICAL_NAMES = {'resnet50': (False, False, False, False), 'resnet101': (False, True, True, False),
+                   'resnet152': (False, True, True, False)}
+
+
+def block_name(backbone, stage, block):
+    """ keras_resnet naming: stage 0..3 -> '2'..'5'; block letter or 'b<k>' """
+    if block > 0 and NUMERICAL_NAMES[backbone][stage]:
+        return '{}b{}'.format(stage + 2, block)
+    return '{}{}'.format(stage + 2, chr(ord('a') + block))
+
+
+def backbone_layers(backbone):
+    """ [(conv name, bn name, KH, KW, C_in, C_out, stride)] of the ResNet, in execution order """
+    layers = [('conv1', 'bn_conv1', 7, 7, 3, 64, 2)]
+    c_in = 64
+    for stage, n_blocks in enumerate(BLOCKS[backbone]):
+        f = 64 * 2 ** stage
+        for block in range(n_blocks):
+            nm = block_name(backbone, stage, block)
+            stride = 2 if (block == 0 and stage > 0) else 1
+            layers.append(('res{}_branch2a'.format(nm), 'bn{}_branch2a'.format(nm), 1, 1, c_in, f, stride))
+            layers.append(('res{}_branch2b'.format(nm), 'bn{}_branch2b'.format(nm), 3, 3, f, f, 1))
+            layers.append(('res{}_branch2c'.format(nm), 'bn{}_branch2c'.format(nm), 1, 1, f, 4 * f, 1))
+            if block == 0:
+                layers.append(('res{}_branch1'.format(nm), 'bn{}_branch1'.format(nm), 1, 1, c_in, 4 * f, stride))
+            c_in = 4 * f
+    return layers
+
+
+def fpn_layers():
+    """ [(name, K, C_in, C_out, stride)] models/retinanet.py:170-205 (feature_size = 512) """
+    return [('C5_reduced', 1, 2048, 512, 1), ('P5', 3, 512, 512, 1), ('C4_reduced', 1, 1024, 512, 1), ('P4', 3, 512, 512, 1),
+            ('C3_reduced', 1, 512, 512, 1), ('P3', 3, 512, 512, 1), ('P6', 3, 2048, 512, 2), ('P7', 3, 512, 512, 2)]
+
+
+def head_layers():
+    """ [(name, C_in, C_out, kind)] all 3x3 stride 1 'same'; kind = 'tower' (ReLU) | 'out' """
+    A = NUM_ANCHORS
+    out = []
+    for i in range(4):
+        out.append(('pyramid_regression_{}'.format(i), 512, 512, 'tower'))
+    out += [('pyramid_regression_op1', 512, 4 * A, 'out')] + [('pyramid_regression_op{}'.format(k), 512, 2 * A, 'out') for k in (2, 3, 4, 5)]
+    for i in range(4):
+        out.append(('pyramid_regression_dim_{}'.format(i), 512 if i == 0 else 128, 128, 'tower'))
+    out.append(('pyramid_regression_dim', 128, 3 * A, 'out'))
+    for i in range(4):
+        out.append(('pyramid_classification_{}'.format(i), 512 if i == 0 else 256, 256, 'tower'))
+    out.append(('pyramid_classification', 256, 8 * A, 'out'))
+    return out
+
+
+def _rng(seed, name):
+    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+
+
+def _normal(seed, name, shape, std):
+    return (_rng(seed, name).standard_normal(size=shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+
+# calibration of the synthetic output layers (measured once with the float32 CPU oracle on a
+# 402x1333 uniform-noise frame; see tests/test_network_oracle.py::test_synthetic_statistics)
+SYN_CLS_OUT_GAIN = 0.182      # classification logits ~ N(-4.6, 0.52): about 1e3 anchors of 137256 above 0.05
+SYN_REG_OUT_GAIN = 0.31       # regression deltas ~ N(0, 1)
+SYN_DIM_OUT_GAIN = 0.18       # dimension deltas ~ N(0, 1)
+
+
+def synthetic_weights(backbone='resnet50', seed=1234):
+    """ Seeded random weights with the exact architecture of `backbone` + FPN + heads. """
+    w = {}
+    for conv, bn, kh, kw, cin, cout, _ in backbone_layers(backbone):
+        w[conv + '/kernel'] = _normal(seed, conv, (kh, kw, cin, cout), np.sqrt(2.0 / (kh * kw * cin)))
+        r = _rng(seed, bn)
+        gamma = (1.0 + 0.1 * r.standard_normal(cout)).astype(np.float32)
+        if bn.endswith('branch2c'):
+            gamma *= np.float32(0.3)          # keeps the residual stream from doubling per block
+        if bn.endswith('branch1'):
+            gamma *= np.float32(0.7)
+        w[bn + '/gamma'] = np.abs(gamma) + np.float32(0.05)
+        w[bn + '/beta'] = (0.05 * r.standard_normal(cout)).astype(np.float32)
+        w[bn + '/moving_mean'] = (0.05 * r.standard_normal(cout)).astype(np.float32)
+        w[bn + '/moving_variance'] = (1.0 + 0.2 * r.random(cout)).astype(np.float32)
+    # the image arrives un-normalised (BGR - mean, +-128): bring conv1 to unit scale
+    w['conv1/kernel'] *= np.float32(1.0 / 64.0)
+    for name, k, cin, cout, _ in fpn_layers():
+        w[name + '/kernel'] = _normal(seed, name, (k, k, cin, cout), np.sqrt(1.0 / (k * k * cin)))
+        w[name + '/bias'] = _normal(seed, name + '/bias', (cout,), 0.01)
+    for name, cin, cout, kind in head_layers():
+        if kind == 'tower':
+            w[name + '/kernel'] = _normal(seed, name, (3, 3, cin, cout), np.sqrt(2.0 / (9 * cin)))
+            w[name + '/bias'] = np.zeros((cout,), np.float32)
+        else:
+            gain = SYN_CLS_OUT_GAIN if 'classification' in name else (SYN_DIM_OUT_GAIN if 'dim' in name else SYN_REG_OUT_GAIN)
+            w[name + '/kernel'] = _normal(seed, name, (3, 3, cin, cout), gain * np.sqrt(1.0 / (9 * cin)))
+            w[name + '/bias'] = np.zeros((cout,), np.float32)
+    # initializers.PriorProbability(0.01): bias = -log((1 - p) / p)   (initializers.py:23-39)
+    w['pyramid_classification/bias'][:] = np.float32(-np.log((1.0 - 0.01) / 0.01))
+    return w
+
+
+def load_weights(path):
+    """ '.npz' written by save_weights, or a Keras '.h5' (needs h5py, absent from this image). """
+    if path.endswith('.npz'):
+        with np.load(path) as z:
+            return {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
+    if path.endswith('.h5') or path.endswith('.hdf5'):
+        try:
+            import h5py
+        except ImportError:
+            raise ImportError('reading a Keras .h5 model needs h5py; convert it to .npz with the layer names '
+                              'documented in keras_retinanet_3D/models/weights.py')
+        out = {}
+        with h5py.File(path, 'r') as f:
+            root = f['model_weights'] if 'model_weights' in f else f
+
+            def visit(name, obj):
+                if isinstance(obj, h5py.Dataset):
+                    parts = name.split('/')
+                    out['{}/{}'.format(parts[-2], parts[-1].split(':')[0])] = np.asarray(obj, dtype=np.float32)
+
+            root.visititems(visit)
+        return out
+    raise ValueError('unknown weight file type: {}'.format(path))
+
+
+def save_weights(path, weights):
+    np.savez(path, **weights)
+
+
+def folded_conv(weights, conv, bn=None):
+    """ (kernel HWIO f32, bias f32) of a convolution with its frozen BatchNormalization folded in:
+        y = gamma * (conv(x) - mean) / sqrt(var + eps) + beta  =  conv(x, k * s) + (beta - mean * s) """
+    k = np.asarray(weights[conv + '/kernel'], dtype=np.float32)
+    if bn is None:
+        return k, np.asarray(weights[conv + '/bias'], dtype=np.float32)
+    s = weights[bn + '/gamma'].astype(np.float64) / np.sqrt(weights[bn + '/moving_variance'].astype(np.float64) + BN_EPSILON)
+    bias = weights[bn + '/beta'].astype(np.float64) - weights[bn + '/moving_mean'].astype(np.float64) * s
+    return (k.astype(np.float64) * s[None, None, None, :]).astype(np.float32), bias.astype(np.float32)
+
+
+def fused_regression_outputs(weights):
+    """ The five regression output convolutions (retinanet.py:112-120) as one C_out = 144 layer,
+    channel order [op1: 4A | op2: 2A | op3: 2A | op4: 2A | op5: 2A]. """
+    names = ['pyramid_regression_op{}'.format(k) for k in (1, 2, 3, 4, 5)]
+    kernel = np.concatenate([weights[n + '/kernel'] for n in names], axis=3)
+    bias = np.concatenate([weights[n + '/bias'] for n in names], axis=0)
+    return kernel.astype(np.float32), bias.astype(np.float32)

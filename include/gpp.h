@@ -150,6 +150,9 @@ int gpp_stem_conv7x7_bn_relu(const float* in, const float* weight, const float* 
                              int B, int H, int W, void* stream);
 int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B, int H, int W, int C, void* stream);
 int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream);
+/* batched form: image b reads `count` elements at in + b*in_bstride, writes out + b*out_bstride */
+int gpp_relu_strided(const void* in, int64_t in_bstride, void* out, int64_t out_bstride, int dtype, int B,
+                     int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Detection decode: sigmoid, orientation fold, score threshold, NMS, top-k, box / dimension
@@ -179,6 +182,51 @@ int gpp_detect_f32(const float* cls_logits, const float* regression, const float
                    float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
                    int32_t* anchor_index, int32_t* counts,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Plan execution: one call enqueues a whole predict_on_batch (every kernel of the graph that
+ * models/retinanet.py:359-422 `retinanet_bbox` builds) from a host array of descriptors.
+ * The runner holds no state: the caller (Python) keeps the descriptors and buffers alive.
+ * Ops whose `tag` is non-zero are bracketed by HIP events when `events` is given: the k-th
+ * tagged op records events[2k] before and events[2k+1] after its launch, on `stream`
+ * (this is how bench.py measures the dominant kernel live inside the timed region).
+ * ---------------------------------------------------------------------------------------- */
+#define GPP_OP_STEM 1
+#define GPP_OP_MAXPOOL 2
+#define GPP_OP_CONV 3
+#define GPP_OP_RELU 4
+#define GPP_OP_DETECT 5
+#define GPP_OP_POLL 6
+
+typedef struct gpp_stem_desc { const float* in; const float* weight; const float* bias; void* out;
+                               int32_t dtype, B, H, W; } gpp_stem_desc;
+typedef struct gpp_pool_desc { const void* in; void* out; int32_t dtype, B, H, W, C, reserved; } gpp_pool_desc;
+typedef struct gpp_relu_desc { const void* in; void* out; int64_t in_bstride, out_bstride, count;
+                               int32_t dtype, B; } gpp_relu_desc;
+typedef struct gpp_detect_desc {
+    const float* cls_logits; const float* regression; const float* regression_dim; const float* anchors;
+    float* boxes; float* dims; float* scores; int32_t* labels; int32_t* orientations;
+    int32_t* anchor_index; int32_t* counts; void* workspace;
+    size_t workspace_bytes; int64_t n_anchors;
+    int32_t B, num_base_anchors, fused_layout, max_det;
+    float score_thr, iou_thr;
+} gpp_detect_desc;
+typedef struct gpp_poll_desc {
+    const float* boxes; const float* dims; const int32_t* orient; const float* P_inv; const float* planes;
+    float* keypoints; float* keyplanes; float* residuals; int32_t* best_idx; void* workspace;
+    size_t workspace_bytes;
+    int32_t B, D, N, planes_batched;
+    float thr; int32_t reserved;
+} gpp_poll_desc;
+
+typedef struct gpp_plan_op { int32_t kind; int32_t tag; const void* desc; } gpp_plan_op;
+
+int gpp_plan_run(const gpp_plan_op* host_ops, int n_ops, void* stream, void* const* events, int n_events);
+
+/* HIP events for callers without HIP headers (bench.py): timing enabled, host handles. */
+int gpp_event_create(void** event);
+int gpp_event_destroy(void* event);
+int gpp_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,135 @@
+"""
+GPU parity of the whole predict_on_batch path against the CPU oracle.
+
+Conv stack (floating point, "parity unpinned" w.r.t. the reference: no keras_resnet / TF here):
+  * against the oracle in 16-bit storage mode (same folded + rounded weights, same rounding of every
+    stored activation, float32 accumulation): head outputs within 2e-2 absolute of O(1) values,
+    median error < 2e-3 -- only summation order and 1-ulp re-rounding separate the two;
+  * against the float32 literal-BatchNormalization oracle: within 0.15 absolute (bf16 storage noise).
+Decode + polling (integer / op-by-op float32 work): bit-exact against the oracle on the GPU's own
+head tensors, which pins the plumbing between the stages.
+"""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import decode_np, net_torch, polling_np
+from keras_retinanet_3D import models
+from keras_retinanet_3D.models import weights as W
+from keras_retinanet_3D.utils import anchors as A
+from keras_retinanet_3D.utils import synthetic
+
+pytestmark = pytest.mark.gpu
+
+MEAN = np.array([103.939, 116.779, 123.68], np.float32)
+
+
+def images(batch, h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=(batch, h, w, 3)).astype(np.float32) - MEAN
+
+
+def unfuse(reg, n_base=12):
+    """ fused conv layout (B, P, 144) -> reference layout (B, A, 12) """
+    B, P, _ = reg.shape
+    op1 = reg[:, :, :4 * n_base].reshape(B, P, n_base, 4)
+    rest = [reg[:, :, 4 * n_base + 2 * n_base * k: 4 * n_base + 2 * n_base * (k + 1)].reshape(B, P, n_base, 2) for k in range(4)]
+    return np.concatenate([op1] + rest, axis=3).reshape(B, P * n_base, 12)
+
+
+@pytest.fixture(scope='module')
+def model50():
+    return models.load_model('synthetic:1234', backbone_name='resnet50')
+
+
+@pytest.mark.parametrize('batch,h,w', [(2, 96, 160), (1, 127, 211)])
+def test_conv_stack_matches_oracle(model50, batch, h, w):
+    weights = W.synthetic_weights('resnet50', 1234)
+    img = images(batch, h, w, seed=h)
+    planes = synthetic.load_plane_database('10').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    plan = model50.stage_inputs([img, np.tile(P_inv[None], (batch, 1, 1)), planes])
+    model50.run_plan(plan)
+    got = {'regression': unfuse(plan.regression.cpu().numpy()),
+           'regression_dim': plan.regression_dim.cpu().numpy().reshape(batch, -1, 3),
+           'classification_logits': plan.cls_logits.cpu().numpy().reshape(batch, -1, 8)}
+    q = net_torch.forward(weights, img, 'resnet50', storage='bf16')
+    f = net_torch.forward(weights, img, 'resnet50', storage=None)
+    for key in got:
+        assert got[key].shape == q[key].shape == f[key].shape
+        eq = np.abs(got[key] - q[key])
+        ef = np.abs(got[key] - f[key])
+        assert eq.max() < 2e-2 and np.median(eq) < 2e-3, (key, eq.max(), np.median(eq))
+        assert ef.max() < 0.15, (key, ef.max())
+
+
+@pytest.mark.parametrize('backbone', ['resnet50', 'resnet101', 'resnet152'])
+def test_predict_on_batch_end_to_end(backbone, oracle_lib):
+    batch, h, w = 2, 128, 224
+    model = models.load_model('synthetic:7', backbone_name=backbone)
+    img = images(batch, h, w, seed=3)
+    planes = synthetic.load_plane_database('1k').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    P_inv = np.tile(P_inv[None].astype(np.float32), (batch, 1, 1))
+    out = model.predict_on_batch([img, P_inv, np.tile(planes[None], (batch, 1, 1))])
+    boxes, dims, scores, labels, orient, keypoints, keyplanes, residuals = out
+    assert [o.shape for o in out] == [(batch, 100, 12), (batch, 100, 3), (batch, 100), (batch, 100), (batch, 100),
+                                      (batch, 100, 4, 3), (batch, 100, 1, 4), (batch, 100)]
+    assert labels.dtype == np.int32 and orient.dtype == np.int32 and boxes.dtype == np.float32
+    assert all(o.flags.writeable for o in out)                       # run_network.py:114 does boxes /= scale
+    assert (scores > 0.05).sum() > 0                                 # synthetic weights produce detections
+
+    # decode + polling replayed by the oracle on the GPU's own head tensors: bit-exact
+    plan = model.plan_for(batch, h, w, 1000, True)
+    anchors = A.anchors_for_image((h, w))
+    det, _ = decode_np.detect(plan.cls_logits.cpu().numpy().reshape(batch, -1, 8), unfuse(plan.regression.cpu().numpy()),
+                              plan.regression_dim.cpu().numpy().reshape(batch, -1, 3), anchors)
+    for got, want in zip(out[:5], det):
+        assert helpers.bits_equal(got, want)
+    kp, kpl, res, idx = helpers.c_oracle_poll(oracle_lib, boxes, dims, orient, P_inv, planes)
+    assert helpers.bits_equal(keypoints, kp) and helpers.bits_equal(keyplanes, kpl) and helpers.bits_equal(residuals, res)
+    assert np.array_equal(plan.best_index.cpu().numpy(), idx)
+
+    # whole path on the CPU (float32 oracle) for the agreement rate of the selected anchors
+    f = net_torch.forward(W.synthetic_weights(backbone, 7), img, backbone)
+    det_cpu, aidx_cpu = decode_np.detect(f['classification_logits'], f['regression'], f['regression_dim'], anchors)
+    aidx_gpu = plan.anchor_index.cpu().numpy()
+    for b in range(batch):
+        a, c = set(aidx_gpu[b][aidx_gpu[b] >= 0].tolist()), set(aidx_cpu[b][aidx_cpu[b] >= 0].tolist())
+        assert len(a & c) >= 0.6 * max(len(c), 1), (len(a), len(c), len(a & c))
+
+
+def test_deterministic_and_shared_planes(model50):
+    batch, h, w = 2, 96, 160
+    img = images(batch, h, w, seed=11)
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    P_inv = np.tile(P_inv[None].astype(np.float32), (batch, 1, 1))
+    a = model50.predict_on_batch([img, P_inv, np.tile(planes[None], (batch, 1, 1))])
+    b = model50.predict_on_batch([img, P_inv, planes])                # (N, 4) database shared by the batch
+    c = model50.predict_on_batch([img, P_inv, np.tile(planes[None], (batch, 1, 1))])
+    for x, y, z in zip(a, b, c):
+        assert helpers.bits_equal(x, y) and helpers.bits_equal(x, z)
+
+
+def test_f16_storage_runs_and_agrees_with_bf16(model50):
+    batch, h, w = 1, 96, 160
+    img = images(batch, h, w, seed=5)
+    planes = synthetic.load_plane_database('10').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    m16 = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='f16')
+    p1 = model50.stage_inputs([img, P_inv[None], planes]); model50.run_plan(p1)
+    p2 = m16.stage_inputs([img, P_inv[None], planes]); m16.run_plan(p2)
+    q = net_torch.forward(W.synthetic_weights('resnet50', 1234), img, 'resnet50', storage='f16')
+    got = p2.cls_logits.cpu().numpy().reshape(batch, -1, 8)
+    assert np.abs(got - q['classification_logits']).max() < 5e-3
+    assert np.abs(got - p1.cls_logits.cpu().numpy().reshape(batch, -1, 8)).max() < 0.1
+
+
+def test_bad_inputs_raise(model50):
+    with pytest.raises(ValueError):
+        model50.predict_on_batch([np.zeros((1, 64, 64, 4), np.float32), np.zeros((1, 4, 3), np.float32), np.ones((4, 4), np.float32)])
+    with pytest.raises(ValueError):
+        model50.predict_on_batch([np.zeros((1, 64, 64, 3), np.float32), np.zeros((2, 4, 3), np.float32), np.ones((4, 4), np.float32)])
+    with pytest.raises(ValueError):
+        models.load_model('synthetic:1', backbone_name='vgg16')
