@@ -208,6 +208,7 @@ class RetinaNet3D(object):
                 x = y
             feats.append(x)
         _, C3, C4, C5 = feats
+        plan.features = {'stem': stem, 'C2': feats[0], 'C3': C3, 'C4': C4, 'C5': C5}
 
         # ---- FPN into one pyramid tensor (B, sum(H_l*W_l), 512)
         shapes = anchor_utils.pyramid_shapes((H, Wd))
@@ -239,6 +240,8 @@ class RetinaNet3D(object):
                                    pix[3] * 512, C.gpp_dtype(self.dtype), B), 'C6_relu')
         self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
                    pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]))
+
+        plan.features.update({'P{}'.format(i + 3): P[i] for i in range(5)})
 
         # ---- heads: every layer is one grouped launch over the five levels
         def tower(prefix, width, tag=0):
