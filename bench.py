@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""
+bench.py -- images/sec end-to-end of the predict_on_batch path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver under torch.distributed.run, one rank per GPU)
+
+A step = one predict_on_batch-equivalent pass (ResNet-50 + FPN + heads + decode/NMS + ground-plane
+polling, 1k-plane database) over a batch of 8 synthetic 1242x375 frames per GPU, already resized to
+the network input 402x1333 and resident in HBM (the reference's own timer, bin/run_network.py:108-111,
+also starts after preprocessing).  N > 1: every rank runs its own 8 images (weak scaling, BASELINE
+config 3 = 64 images over 8 GPUs) and the step ends with ONE all-gather of the packed detections.
+
+The JSON line also carries
+  roofline      the dominant kernel = conv_igemm_kernel on the 3x3 512->512 regression-tower layers
+                (45 % of all FLOPs): algorithmic FLOPs per launch / mean launch duration measured with
+                HIP events inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak
+  cpu_baseline  the CPU oracle (torch float32 restatement + NumPy decode + C polling) timed on this
+                host on a bounded sample -- "CPU restatement, not TF1" (TF1 cannot be installed)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'ground-plane-polling_amd'))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+MEAN = np.array([103.939, 116.779, 123.68], np.float32)
+PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0}     # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=30)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    p.add_argument('--backbone', default='resnet50')
+    p.add_argument('--planes', default='1k')
+    p.add_argument('--dtype', default='bf16')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-images', type=int, default=2)
+    return p.parse_args()
+
+
+def synthetic_batch(batch, rank):
+    """ uint8 noise frames 375x1242, 'resized' to the network input 402x1333 (nearest, host side,
+    outside the timed region), BGR mean subtracted -- the tensor predict_on_batch receives """
+    from keras_retinanet_3D.utils import synthetic
+    out = np.empty((batch, 402, 1333, 3), np.float32)
+    ys = np.minimum((np.arange(402) * (375.0 / 402.0)).astype(np.int64), 374)
+    xs = np.minimum((np.arange(1333) * (1242.0 / 1333.0)).astype(np.int64), 1241)
+    for i in range(batch):
+        frame = synthetic.synthetic_image(seed=1000 * rank + i)
+        out[i] = frame[ys][:, xs].astype(np.float32) - MEAN
+    return out
+
+
+def cpu_baseline(n_images, backbone, planes):
+    """ whole path on the host cores with the oracle (bounded sample) """
+    import torch
+    from oracle import decode_np, net_torch
+    from keras_retinanet_3D.models import weights as W
+    from keras_retinanet_3D.utils import anchors as A
+    from keras_retinanet_3D.utils import synthetic
+    import ctypes
+    import subprocess
+    lib_path = os.path.join(ROOT, 'oracle', 'liboracle_polling.so')
+    if not os.path.isfile(lib_path):
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(lib_path)
+    weights = W.synthetic_weights(backbone, 1234)
+    net = net_torch.Net(weights, backbone)
+    anchors = A.anchors_for_image((402, 1333))
+    _, P_inv = synthetic.synthetic_calibration()
+    P_inv = P_inv[None].astype(np.float32)
+    img = synthetic_batch(1, 0)
+    net.forward(img[:, :64, :96])                    # warm the thread pool
+    t0 = time.perf_counter()
+    for i in range(n_images):
+        f = net.forward(synthetic_batch(1, 77 + i))
+        det, _ = decode_np.detect(f['classification_logits'], f['regression'], f['regression_dim'], anchors)
+        boxes, dims, orient = det[0], det[1], det[4]
+        kp = np.empty((1, 100, 4, 3), np.float32)
+        kpl = np.empty((1, 100, 1, 4), np.float32)
+        res = np.empty((1, 100), np.float32)
+        idx = np.empty((1, 100), np.int32)
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        lib.gpp_oracle_poll_f32(ptr(boxes), ptr(dims), ptr(orient), ptr(P_inv), ptr(planes), 1, 100, planes.shape[0], 0,
+                                ctypes.c_float(0.7), ptr(kp), ptr(kpl), ptr(res), ptr(idx))
+    dt = time.perf_counter() - t0
+    return {'value': round(n_images / dt, 4), 'unit': 'images/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': '{} synthetic 402x1333 frames, batch 1, whole path (torch-CPU float32 conv stack + NumPy decode/NMS + '
+                      'C polling, {} planes); CPU restatement, not TF1'.format(n_images, planes.shape[0])}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    from keras_retinanet_3D import models
+    from keras_retinanet_3D.backend import hip
+    from keras_retinanet_3D.utils import synthetic
+    from keras_retinanet_3D.utils import distributed as D
+    import ctypes
+
+    model = models.load_model('synthetic:1234', backbone_name=args.backbone, dtype=args.dtype)
+    planes = synthetic.load_plane_database(args.planes).astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    B = args.batch
+    images = torch.as_tensor(synthetic_batch(B, rank)).cuda()
+    P_inv_d = torch.as_tensor(np.tile(P_inv[None].astype(np.float32), (B, 1, 1))).cuda()
+    planes_d = torch.as_tensor(np.tile(planes[None], (B, 1, 1))).cuda()      # tiled per image, as kitti.py:220
+    plan = model.stage_inputs([images, P_inv_d, planes_d])                    # inputs resident in HBM from here on
+    torch.cuda.synchronize()
+
+    lib = hip.lib()
+    n_tagged = len(plan.tagged)
+    events = []
+    for _ in range(2 * n_tagged * args.steps):
+        e = ctypes.c_void_p()
+        hip.check(lib.gpp_event_create(ctypes.byref(e)))
+        events.append(e)
+
+    def step(k=None):
+        ev = None if k is None else [e.value for e in events[2 * n_tagged * k: 2 * n_tagged * (k + 1)]]
+        model.run_plan(plan, ev)
+        packed = D.pack_outputs(model.outputs(plan))
+        return D.gather_detections(packed) if world > 1 else packed
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: mean launch duration from the HIP events recorded inside the timed region
+    durations = []
+    for i in range(0, len(events), 2):
+        ms = ctypes.c_float(0.0)
+        hip.check(lib.gpp_event_elapsed_ms(events[i], events[i + 1], ctypes.byref(ms)))
+        durations.append(ms.value)
+    tagged_flops = [fl for _, tag, _, _, fl in plan.ops if tag]
+    flops_per_launch = float(np.mean(tagged_flops)) if tagged_flops else 0.0
+    mean_ms = float(np.mean(durations)) if durations else float('nan')
+    achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12 if durations else float('nan')
+    counts = plan.counts.cpu().numpy()
+    dets = int((out[:, :, 15] > 0.05).sum().item())
+
+    if rank == 0:
+        total_images = world * B * args.steps
+        rec = {
+            'metric': 'images/sec end-to-end ({}, {} planes, 1242x375)'.format(args.backbone, args.planes),
+            'value': round(total_images / elapsed, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'batch={} synthetic 1242x375 frames per GPU (network input 402x1333, resident in HBM), '
+                                   '{} + FPN + heads + decode/NMS + polling, {}-plane database ({} planes), seeded random weights'.format(
+                                       B, args.backbone, args.planes, planes.shape[0]),
+                       'global_batch': world * B, 'parallelism': 'dp{} image shards, one all_gather of (B,100,35) f32'.format(world),
+                       'candidates_per_image': [int(c) for c in counts], 'detections_rank0': dets,
+                       'algorithmic_gflop_per_image': round(plan.flops / B / 1e9, 1),
+                       'achieved_tflops_whole_path': round(plan.flops * args.steps / elapsed / 1e12, 1)},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': None,
+                         'kernel': 'conv_igemm_kernel<{},128,128> on pyramid_regression_0..3 (3x3, 512->512, 5 levels, M={})'.format(
+                             args.dtype, B * (plan.n_anchors // 12)),
+                         'gflop_per_launch': round(flops_per_launch / 1e9, 1), 'mean_launch_ms': round(mean_ms, 4),
+                         'launches_timed': len(durations)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec['cpu_baseline'] = cpu_baseline(args.cpu_images, args.backbone, planes)
+        print(json.dumps(rec))
+    for e in events:
+        lib.gpp_event_destroy(e)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,88 @@
+"""
+Image-sharded data-parallel inference: one process per GPU, one collective per step.
+
+The reference has no inference-time parallelism at all (its only multi-device code is the training
+helper keras.utils.multi_gpu_model, bin/train.py:100-104).  The path shards trivially because every
+stage keeps the batch dimension (FilterDetections is a per-image map_fn,
+layers/filter_detections.py:257-262; polling is per (image, detection)): rank r of W ranks takes
+the contiguous images [r*B/W, (r+1)*B/W), weights and the plane database are replicated, and the
+only exchange is ONE all-gather of the packed final detections, 100 x 35 float32 = 14 000 bytes per
+image (RCCL over xGMI under torch.distributed backend 'nccl'; latency-bound at this size).
+No reduction takes place, so the gathered result is bit-identical to a single-GPU run.
+"""
+
+import numpy as np
+
+PACK_WIDTH = 35      # 12 box + 3 dim + score + label + orientation + 12 keypoints + 4 plane + residual
+_SLICES = [(0, 12), (12, 15), (15, 16), (16, 17), (17, 18), (18, 30), (30, 34), (34, 35)]
+_SHAPES = [(12,), (3,), (), (), (), (4, 3), (1, 4), ()]
+
+
+def shard_range(global_batch, rank, world_size):
+    """ contiguous split; the first (global_batch % world_size) ranks take one extra image """
+    base, extra = divmod(int(global_batch), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def pack_outputs(outputs):
+    """ the 8 model outputs (torch tensors) -> one (B, 100, 35) float32 tensor (ints are small: exact) """
+    import torch
+    b, d = outputs[0].shape[:2]
+    return torch.cat([o.reshape(b, d, -1).to(torch.float32) for o in outputs], dim=2).contiguous()
+
+
+def unpack_outputs(packed):
+    """ inverse of pack_outputs; NumPy arrays with the reference's dtypes (labels / orientations int32) """
+    import torch
+    arr = packed.cpu().numpy() if isinstance(packed, torch.Tensor) else np.asarray(packed)
+    out = []
+    for k, ((lo, hi), shp) in enumerate(zip(_SLICES, _SHAPES)):
+        a = np.ascontiguousarray(arr[:, :, lo:hi]).reshape(arr.shape[:2] + shp)
+        out.append(a.astype(np.int32) if k in (3, 4) else a.astype(np.float32))
+    return out
+
+
+def gather_detections(packed_local, shard_sizes=None, group=None):
+    """ all-gather the packed detections of every rank -> (B_global, 100, 35) on every rank """
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return packed_local
+    world = dist.get_world_size(group)
+    if shard_sizes is None:
+        shard_sizes = [packed_local.shape[0]] * world
+    equal = len(set(shard_sizes)) == 1
+    if equal and dist.get_backend(group) == 'nccl':
+        out = torch.empty((sum(shard_sizes),) + tuple(packed_local.shape[1:]), dtype=packed_local.dtype, device=packed_local.device)
+        dist.all_gather_into_tensor(out, packed_local, group=group)
+        return out
+    pad = max(shard_sizes)
+    local = packed_local
+    if local.shape[0] < pad:
+        local = torch.cat([local, local.new_zeros((pad - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+    chunks = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(chunks, local.contiguous(), group=group)
+    return torch.cat([c[:n] for c, n in zip(chunks, shard_sizes)], dim=0)
+
+
+class ShardedModel(object):
+    """ Wraps a model: predict_on_batch on a GLOBAL batch, each rank computing its contiguous shard. """
+
+    def __init__(self, model, group=None):
+        self.model = model
+        self.group = group
+
+    def predict_on_batch(self, inputs):
+        import torch.distributed as dist
+        images, P_inv, planes = inputs
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        B = images.shape[0]
+        lo, hi = shard_range(B, rank, world)
+        local_planes = planes[lo:hi] if len(planes.shape) == 3 else planes
+        plan = self.model.stage_inputs([images[lo:hi], P_inv[lo:hi], local_planes])
+        self.model.run_plan(plan)
+        packed = pack_outputs(self.model.outputs(plan))
+        sizes = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
+        return unpack_outputs(gather_detections(packed, sizes, self.group))
