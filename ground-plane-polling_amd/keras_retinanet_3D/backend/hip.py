@@ -106,6 +106,10 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             raise GppError('{} not found: build it with `make -C {}` (or __graft_entry__.build()); '
                            'there is no CPU fallback for the HIP path'.format(LIB_PATH, CSRC_DIR))
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the HIP runtime already in the
+        # process when libgpp_hip.so (linked against the same soname) is loaded, otherwise two
+        # runtimes coexist and the kernels see no device (hipErrorNoDevice).
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         _declare(handle)
         _LIB = handle
