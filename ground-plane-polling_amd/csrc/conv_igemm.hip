@@ -21,7 +21,8 @@
 //   ds_read_b128 fragment reads conflict-free (bank = (addr/4) % 64, 16-lane groups).
 //   Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous range of
 //   tiles; the N-tiles of one M-tile are adjacent, so the activation rows are shared in L2.
-//   Epilogue: accumulators -> LDS (per-wave private slab) -> 16-byte coalesced row stores.
+//   Epilogue: straight from the accumulators (operands swapped + host-interleaved weight rows give
+//   every lane 8 consecutive output channels): bias, residual (+ nearest resize), ReLU, 16-byte stores.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,15 +53,19 @@ template <> struct Elem<GPP_F16> {
     }
 };
 
-constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;     // one K-step of one tile row: 64 two-byte elements
-constexpr int kEpiPitch = 68;      // floats per row of the epilogue slab (64 + 4 pad)
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base)
+// LDS-DMA through a buffer descriptor: 16 bytes per lane from base + voffset + soffset to
+// lds_dst_wave_base + lane*16.  voffset is per lane, soffset wave-uniform (SGPR), so the per-K-step
+// address arithmetic is scalar; a lane whose voffset is out of range (kOutOfRange) gets zeros,
+// which is how convolution padding is produced without a zero page or per-step predication.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, void* lds_dst_wave_base)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16,
+                                             voffset, soffset, 0, 0);
 }
+
+constexpr int kOutOfRange = (int)0x80000000;
 
 // Bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous tile range.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
@@ -70,22 +75,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-template <int DT, int BM, int BN>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const gpp_conv_desc d)
+template <int DT, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_conv_desc d)
 {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
     using scalar = typename E::scalar;
-    constexpr int MF = BM / 32, NF = BN / 32;          // 16x16 accumulators per wave: MF x NF
+    constexpr int NW = WM * WN;                          // wavefronts per workgroup
+    constexpr int MF = BM / WM / 16, NF = BN / WN / 16;  // 16x16 accumulators per wave: MF x NF
     constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;      // LDS-DMA instructions per wave per stage
-    static_assert(2 * STAGE >= 4 * 32 * kEpiPitch * 4, "epilogue slab must fit in the staging LDS");
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;   // LDS-DMA instructions per wave per stage
+    constexpr int PER_STAGE = A_IT + B_IT;
+    constexpr int PF = STAGES - 1;                       // K-steps in flight ahead of the one computed
+    static_assert(MF % 2 == 0 && MF >= 2 && NF >= 1 && A_IT >= 1 && B_IT >= 1, "tile / wave shape");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // ---- which tile
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -113,42 +121,48 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const gpp_conv_
     const int nk = d.KH * d.KW * cpt;
 
     // ---- staging bookkeeping: this lane owns LDS chunk (row srow of each 8-row piece, slot lane&7)
+    // and fetches source chunk gchunk = slot ^ srow (inverse of the read swizzle).  Byte offsets are
+    // relative to d.in / d.weight and go through buffer descriptors (32-bit, range checked).
     const int srow = lane >> 3;
-    const int gchunk = (lane & 7) ^ srow;               // source chunk: inverse of the read swizzle
-    const scalar* in = (const scalar*)d.in;
-    const scalar* zero = (const scalar*)d.zero_page + gchunk * 8;
-    int64_t a_base[A_IT];
-    int a_iy0[A_IT], a_ix0[A_IT];
+    const int gchunk = (lane & 7) ^ srow;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, d.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.weight, 0, d.weight_bytes, 0x00020000);
+    int a_rowbase[A_IT], a_iy0[A_IT], a_ix0[A_IT], a_voff[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + wave * (BM / 4) + i * 8 + srow;
+        const int m = m0 + (wave * A_IT + i) * 8 + srow;
         if (m < Mg) {
             const int b = m / HoWo, p = m - b * HoWo;
             const int oy = p / W_out, ox = p - oy * W_out;
             a_iy0[i] = oy * d.stride - d.pad_top;
             a_ix0[i] = ox * d.stride - d.pad_left;
-            a_base[i] = in_off + (int64_t)b * in_bs + gchunk * 8;
+            a_rowbase[i] = (int)((in_off + (int64_t)b * in_bs) * 2) + gchunk * 16;
         } else {
-            a_iy0[i] = -(1 << 28); a_ix0[i] = 0; a_base[i] = 0;
+            a_iy0[i] = -(1 << 28); a_ix0[i] = 0; a_rowbase[i] = 0;
         }
     }
-    const scalar* w_src[B_IT];
+    int w_voff[B_IT];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-        w_src[i] = (const scalar*)d.weight + (int64_t)(n0 + wave * (BN / 4) + i * 8 + srow) * Ktot + gchunk * 8;
+    for (int i = 0; i < B_IT; ++i) w_voff[i] = (n0 + (wave * B_IT + i) * 8 + srow) * Ktot * 2 + gchunk * 16;
+    const int pitch2 = d.in_pitch * 2;
 
-    auto stage = [&](int buf, int kh, int kw, int cc, int ks) {
-        unsigned char* sa = smem + buf * STAGE + wave * (BM / 4) * kRowBytes;
-        unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * (BN / 4) * kRowBytes;
+    // per tap (every cpt K-steps): where this lane's rows read from, or kOutOfRange for padding
+    auto set_tap = [&](int kh, int kw) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
             const bool ok = (unsigned)iy < (unsigned)H_in && (unsigned)ix < (unsigned)W_in;
-            const scalar* src = ok ? in + a_base[i] + ((int64_t)iy * W_in + ix) * d.in_pitch + cc * 64 : zero;
-            glds16(src, sa + i * 8 * kRowBytes);
+            a_voff[i] = ok ? a_rowbase[i] + (iy * W_in + ix) * pitch2 : kOutOfRange;
         }
+    };
+    // per K-step: only scalar offsets change (cc*128 bytes into the pixel, ks*128 bytes into the weight row)
+    auto stage = [&](int buf, int cc, int ks) {
+        unsigned char* sa = smem + buf * STAGE + wave * A_IT * 8 * kRowBytes;
+        unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(w_src[i] + (int64_t)ks * 64, sb + i * 8 * kRowBytes);
+        for (int i = 0; i < A_IT; ++i) glds16(in_rsrc, a_voff[i], cc * kRowBytes, sa + i * 8 * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16(w_rsrc, w_voff[i], ks * kRowBytes, sb + i * 8 * kRowBytes);
     };
 
     // ---- fragment read offsets (bytes inside a stage)
@@ -157,8 +171,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const gpp_conv_
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int sw = ((kk * 4 + fq) ^ (frow & 7)) << 4;
-        a_rd[kk] = (wm * (BM / 2) + frow) * kRowBytes + sw;
-        b_rd[kk] = A_BYTES + (wn * (BN / 2) + frow) * kRowBytes + sw;
+        a_rd[kk] = (wm * (BM / WM) + frow) * kRowBytes + sw;
+        b_rd[kk] = A_BYTES + (wn * (BN / WN) + frow) * kRowBytes + sw;
     }
 
     f32x4 acc[MF][NF];
@@ -167,18 +181,40 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const gpp_conv_
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- main loop: stage k+1 while computing k; one barrier per K-step
-    int kh = 0, kw = 0, cc = 0;
-    stage(0, kh, kw, cc, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) {
-            if (++cc == cpt) { cc = 0; if (++kw == d.KW) { kw = 0; ++kh; } }
-            stage(cur ^ 1, kh, kw, cc, ks + 1);
+    // ---- main loop.  Ring of STAGES buffers, PF = STAGES-1 K-steps of LDS-DMA in flight; one raw
+    // s_barrier per K-step.  At the top of step ks a counted vmcnt retires this wave's loads of
+    // stage ks only (later stages stay in flight across the barrier); after the barrier every
+    // wave's loads of stage ks have landed and every wave has finished reading the buffer of step
+    // ks-1, which is exactly the buffer the next prefetch (stage ks+PF) overwrites.
+    int kh = 0, kw = 0, cc = 0, issued = 0, ibuf = 0;
+    set_tap(0, 0);
+    auto issue_next = [&]() {
+        stage(ibuf, cc, issued);
+        if (++cc == cpt) {
+            cc = 0;
+            if (++kw == d.KW) { kw = 0; ++kh; }
+            set_tap(kh, kw);
         }
-        const unsigned char* sbase = smem + cur * STAGE;
+        ++issued;
+        if (++ibuf == STAGES) ibuf = 0;
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (issued < nk) issue_next();
+    int cbuf = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (issued - ks - 1 >= PF - 1 && PF > 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * PER_STAGE) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < nk) {
+            if (d.reserved & 1) { ++issued; } else issue_next();      // bit 0 (diagnostic): skip the LDS-DMA
+        }
+        const unsigned char* sbase = smem + cbuf * STAGE;
+        if (!(d.reserved & 2))                                         // bit 1 (diagnostic): skip LDS reads + MFMA
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             vec8 af[MF], bfr[NF];
@@ -189,120 +225,146 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const gpp_conv_
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = E::mfma(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < NF; ++j) acc[i][j] = E::mfma(bfr[j], af[i], acc[i][j]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (++cbuf == STAGES) cbuf = 0;
     }
-
-    // ---- epilogue: per-wave slab of 32 rows x 64 cols float32, two (MF > 2: MF/2) passes
-    float* slab = (float*)smem + wave * (32 * kEpiPitch);
-    const int erow = lane >> 3, ecol = (lane & 7) * 8;
-    constexpr int COLS = BN / 2;                         // columns owned by this wave (64 or 32)
+    // ---- epilogue, straight from registers.  The MFMA was issued as D = W_tile * X_tile^T, so
+    // lane (fq = lane>>4, c = lane&15) of accumulator (i, j) holds output pixel i*16 + c and the four
+    // weight-tile rows fq*4 + 0..3 of N-tile j.  The packed weight rows are interleaved on the host
+    // (row 16h + 4q + r of every 32-row group = output channel 8q + 4h + r), hence tiles 2jj and
+    // 2jj+1 together give this lane EIGHT CONSECUTIVE output channels n = n0 + 32jj + 8fq + 0..7:
+    // one 16-byte store (two for float32 output), no LDS round trip.
+    constexpr int COLS = BN / WN;                        // output channels owned by this wave
+    static_assert(NF % 2 == 0, "N tiles come in interleaved pairs");
     const scalar* res = (const scalar*)d.residual;
     const bool resize = (H_res != H_out) || (W_res != W_out);
     const float sy = resize ? (float)H_res / (float)H_out : 1.0f;
     const float sx = resize ? (float)W_res / (float)W_out : 1.0f;
+    float bias_v[NF / 2][8];
 #pragma unroll
-    for (int half = 0; half < MF / 2; ++half) {
+    for (int jj = 0; jj < NF / 2; ++jj) {
+        const int n = n0 + wn * COLS + jj * 32 + fq * 8;
 #pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
+        for (int e = 0; e < 8; ++e) bias_v[jj][e] = (d.bias && n + e < d.C_out) ? d.bias[n + e] : 0.0f;
+    }
 #pragma unroll
-            for (int j = 0; j < NF; ++j)
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+        if (m >= Mg) continue;
+        const int b = m / HoWo, p = m - b * HoWo;
+        int64_t rp = p;
+        if (res && resize) {
+            const int oy = p / W_out, ox = p - oy * W_out;
+            const int ry = min((int)floorf((float)oy * sy), H_res - 1);
+            const int rx = min((int)floorf((float)ox * sx), W_res - 1);
+            rp = (int64_t)ry * W_res + rx;
+        }
+        const int64_t obase = out_off + (int64_t)b * out_bs + (int64_t)p * d.out_pitch;
+        const scalar* rrow = res ? res + res_off + (int64_t)b * res_bs + rp * d.res_pitch : nullptr;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    slab[(i2 * 16 + fq * 4 + r) * kEpiPitch + j * 16 + frow] = acc[half * 2 + i2][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (ecol < COLS) {
+        for (int jj = 0; jj < NF / 2; ++jj) {
+            const int n = n0 + wn * COLS + jj * 32 + fq * 8;
+            if (n >= d.C_out) continue;
+            const bool full = (n + 8 <= d.C_out);
+            float v[8];
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int lr = pass * 8 + erow;
-                const int m = m0 + wm * (BM / 2) + half * 32 + lr;
-                const int n = n0 + wn * COLS + ecol;
-                if (m < Mg && n < d.C_out) {
-                    const int b = m / HoWo, p = m - b * HoWo;
-                    float v[8];
-                    const f32x4 v0 = *(const f32x4*)(slab + lr * kEpiPitch + ecol);
-                    const f32x4 v1 = *(const f32x4*)(slab + lr * kEpiPitch + ecol + 4);
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
+                v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
+            }
+            if (rrow) {
+                if (full) {
+                    const vec8 rv = *(const vec8*)(rrow + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-                    const bool full = (n + 8 <= d.C_out);
-                    if (d.bias) {
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                } else {
+                    for (int e = 0; e < 8 && n + e < d.C_out; ++e) v[e] += (float)rrow[n + e];
+                }
+            }
+            if (d.relu) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) if (full || n + e < d.C_out) v[e] += d.bias[n + e];
-                    }
-                    if (res) {
-                        int64_t rp = p;
-                        if (resize) {
-                            const int oy = p / W_out, ox = p - oy * W_out;
-                            const int ry = min((int)floorf((float)oy * sy), H_res - 1);
-                            const int rx = min((int)floorf((float)ox * sx), W_res - 1);
-                            rp = (int64_t)ry * W_res + rx;
-                        }
-                        const scalar* rsrc = res + res_off + (int64_t)b * res_bs + rp * d.res_pitch + n;
-                        if (full) {
-                            const vec8 rv = *(const vec8*)rsrc;
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+            }
+            if (d.out_f32) {
+                float* dst = (float*)d.out + obase + n;
+                if (full) {
+                    *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = v[e];
+                }
+            } else {
+                scalar* dst = (scalar*)d.out + obase + n;
+                if (full) {
+                    vec8 ov;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-                        } else {
-                            for (int e = 0; e < 8 && n + e < d.C_out; ++e) v[e] += (float)rsrc[e];
-                        }
-                    }
-                    if (d.relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-                    }
-                    const int64_t o = out_off + (int64_t)b * out_bs + (int64_t)p * d.out_pitch + n;
-                    if (d.out_f32) {
-                        float* dst = (float*)d.out + o;
-                        if (full) {
-                            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-                            *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                        } else {
-                            for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = v[e];
-                        }
-                    } else {
-                        scalar* dst = (scalar*)d.out + o;
-                        if (full) {
-                            vec8 ov;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) ov[e] = (scalar)v[e];
-                            *(vec8*)dst = ov;
-                        } else {
-                            for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = (scalar)v[e];
-                        }
-                    }
+                    for (int e = 0; e < 8; ++e) ov[e] = (scalar)v[e];
+                    *(vec8*)dst = ov;
+                } else {
+                    for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = (scalar)v[e];
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
-template <int DT, int BM, int BN>
-int launch(const gpp_conv_desc& d, int total_tiles, hipStream_t st)
+// One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.
+template <int DT, int BM, int BN, int WM, int WN, int STAGES>
+int launch(gpp_conv_desc& d, hipStream_t st)
 {
-    constexpr int lds = 2 * (BM + BN) * kRowBytes;
+    constexpr int lds = STAGES * (BM + BN) * kRowBytes;
     static bool configured = false;
-    auto kernel = conv_igemm_kernel<DT, BM, BN>;
+    auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
+    if (d.weight_rows < ((d.C_out + BN - 1) / BN) * BN) return GPP_ERR_BAD_ARG;
+    int64_t in_elems = 0;
+    for (int g = 0; g < d.n_groups; ++g) {
+        const gpp_conv_group& G = d.groups[g];
+        const int64_t end = G.in_off + (int64_t)(d.batch - 1) * G.in_bstride + ((int64_t)G.H_in * G.W_in - 1) * d.in_pitch + d.C_in;
+        if (G.in_off < 0 || G.in_bstride < 0) return GPP_ERR_BAD_ARG;
+        in_elems = end > in_elems ? end : in_elems;
+    }
+    const int64_t w_bytes = (int64_t)d.weight_rows * d.KH * d.KW * d.C_in * 2;
+    if (in_elems * 2 >= (1LL << 31) || w_bytes >= (1LL << 31)) return GPP_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+    d.in_bytes = (int32_t)(in_elems * 2);
+    d.weight_bytes = (int32_t)w_bytes;
+    int tiles = 0;
+    for (int g = 0; g < d.n_groups; ++g) {
+        d.groups[g].tile_start = tiles;
+        tiles += (d.batch * d.groups[g].H_out * d.groups[g].W_out + BM - 1) / BM;
+    }
     const int n_tiles = (d.C_out + BN - 1) / BN;
-    kernel<<<dim3((unsigned)(total_tiles * n_tiles)), dim3(kThreads), lds, st>>>(d);
+    kernel<<<dim3((unsigned)(tiles * n_tiles)), dim3(64 * WM * WN), lds, st>>>(d);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }
 
+template <int DT>
+int dispatch(gpp_conv_desc& d, hipStream_t st)
+{
+    const bool narrow = d.C_out <= 64 || (d.C_out % 128 != 0 && d.C_out % 128 <= 64);
+    int64_t rows = 0;
+    for (int g = 0; g < d.n_groups; ++g) rows += (int64_t)d.batch * d.groups[g].H_out * d.groups[g].W_out;
+    const int nk = d.KH * d.KW * (d.C_in / 64);
+    if (narrow) return launch<DT, 128, 64, 2, 2, 2>(d, st);
+    // 256x256 tile (8 wavefronts, 1 workgroup / CU) halves the L2 -> LDS traffic per FLOP; it pays
+    // when there are enough tiles for two rounds over the 256 CUs and enough K-steps to amortise
+    // its longer prologue/epilogue.  (256x128 with a 3-deep ring is kept for experiments only.)
+    const int64_t big_blocks = ((rows + 255) / 256) * (d.C_out / 256);
+    if (d.tile_hint == 512 || (d.tile_hint == 0 && d.C_out % 256 == 0 && big_blocks >= 512 && nk >= 8))
+        return launch<DT, 256, 256, 2, 4, 2>(d, st);
+    if (d.tile_hint == 256) return launch<DT, 256, 128, 4, 2, 3>(d, st);
+    return launch<DT, 128, 128, 2, 2, 2>(d, st);
+}
+
 int validate(const gpp_conv_desc& d)
 {
-    if (!d.in || !d.weight || !d.out || !d.zero_page) return GPP_ERR_BAD_ARG;
+    if (!d.in || !d.weight || !d.out) return GPP_ERR_BAD_ARG;
     if (d.dtype != GPP_BF16 && d.dtype != GPP_F16) return GPP_ERR_UNSUPPORTED;
     if (d.batch <= 0 || d.C_in <= 0 || d.C_out <= 0 || d.KH <= 0 || d.KW <= 0) return GPP_ERR_BAD_ARG;
     if (d.C_in % 64 != 0 || d.C_out % 4 != 0) return GPP_ERR_UNSUPPORTED;
@@ -344,16 +406,6 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
     gpp_conv_desc d = *host_desc;
     int rc = validate(d);
     if (rc != GPP_OK) return rc;
-    constexpr int BM = 128;
-    const bool narrow = d.C_out <= 64 || (d.C_out % 128 != 0 && d.C_out % 128 <= 64);
-    const int BN = narrow ? 64 : 128;
-    if (d.weight_rows < ((d.C_out + BN - 1) / BN) * BN) return GPP_ERR_BAD_ARG;
-    int tiles = 0;
-    for (int g = 0; g < d.n_groups; ++g) {
-        d.groups[g].tile_start = tiles;
-        tiles += (d.batch * d.groups[g].H_out * d.groups[g].W_out + BM - 1) / BM;
-    }
     hipStream_t st = (hipStream_t)stream;
-    if (d.dtype == GPP_BF16) return narrow ? launch<GPP_BF16, 128, 64>(d, tiles, st) : launch<GPP_BF16, 128, 128>(d, tiles, st);
-    return narrow ? launch<GPP_F16, 128, 64>(d, tiles, st) : launch<GPP_F16, 128, 128>(d, tiles, st);
+    return d.dtype == GPP_BF16 ? dispatch<GPP_BF16>(d, st) : dispatch<GPP_F16>(d, st);
 }

@@ -60,6 +60,8 @@ class ConvDesc(ctypes.Structure):
                 ('pad_top', ctypes.c_int32), ('pad_left', ctypes.c_int32),
                 ('in_pitch', ctypes.c_int32), ('out_pitch', ctypes.c_int32), ('res_pitch', ctypes.c_int32),
                 ('weight_rows', ctypes.c_int32), ('relu', ctypes.c_int32), ('n_groups', ctypes.c_int32),
+                ('tile_hint', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('in_bytes', ctypes.c_int32), ('weight_bytes', ctypes.c_int32),
                 ('groups', ConvGroup * GPP_MAX_GROUPS)]
 
 

@@ -48,14 +48,26 @@ class FMap(object):
 
 def pack_weight(kernel_hwio, dtype, device):
     """ Keras HWIO float32 kernel (KH, KW, C_in, C_out) -> device tensor
-    [C_out rounded up to 128][KH*KW*C_in] in the compute type, K ordered (kh, kw, c_in). """
+    [C_out rounded up to 256][KH*KW*C_in] in the compute type, K ordered (kh, kw, c_in). """
     import torch
     k = torch.as_tensor(np.ascontiguousarray(kernel_hwio, dtype=np.float32))
     KH, KW, Cin, Cout = k.shape
-    rows = ((Cout + 127) // 128) * 128
+    rows = ((Cout + 255) // 256) * 256
     w = torch.zeros((rows, KH * KW * Cin), dtype=torch.float32)
     w[:Cout] = k.permute(3, 0, 1, 2).reshape(Cout, KH * KW * Cin)
+    w = w[weight_row_order(rows)]
     return w.to(torch_dtype(dtype)).to(device).contiguous()
+
+
+def weight_row_order(rows):
+    """ Row interleave the kernel expects (include/gpp.h): within every group of 32 output channels,
+    stored row 16*h + 4*q + r holds output channel 8*q + 4*h + r (h in 0..1, q in 0..3, r in 0..3), so
+    that the two MFMA tiles of a pair hand each lane 8 consecutive output channels. """
+    import torch
+    pos = torch.arange(rows)
+    g, within = pos // 32, pos % 32
+    h, q, r = within // 16, (within % 16) // 4, within % 4
+    return g * 32 + 8 * q + 4 * h + r
 
 
 _ZERO_PAGES = {}
@@ -77,7 +89,7 @@ def same_pad(in_size, k, stride):
 
 
 def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=(0, 0), relu=False,
-              residuals=None, dtype='bf16', out_f32=False):
+              residuals=None, dtype='bf16', out_f32=False, tile_hint=0, diag=0):
     """ Build a gpp_conv_desc.  inputs / outputs / residuals are lists of FMap (one per group,
     all groups share weights; every list member must live in the same torch buffer). """
     d = hip.ConvDesc()
@@ -98,6 +110,8 @@ def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=
     d.weight_rows = int(weight.shape[0])
     d.relu = int(relu)
     d.n_groups = len(inputs)
+    d.tile_hint = int(tile_hint)
+    d.reserved = int(diag)          # diagnostic ablation bits (timing experiments only)
     assert 1 <= len(inputs) <= hip.GPP_MAX_GROUPS and len(outputs) == len(inputs)
     assert int(weight.shape[1]) == KH * KW * C_in
     for g, (fi, fo) in enumerate(zip(inputs, outputs)):

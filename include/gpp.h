@@ -88,19 +88,22 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
  * Layouts (element = 2 bytes, GPP_BF16 or GPP_F16)
  *   in        pixel (b, y, x) of a group at  in + in_off + b*in_bstride + (y*W_in + x)*in_pitch,
  *             C_in contiguous channels there (in_pitch >= C_in lets a channel slice be read)
- *   weight    [C_out rounded up to a multiple of 128][KH*KW*C_in], K contiguous; rows >= C_out
- *             must exist (zero) -- weight_rows states how many rows are allocated
+ *   weight    [C_out rounded up to a multiple of 256][KH*KW*C_in], K contiguous; rows >= C_out
+ *             must exist (zero) -- weight_rows states how many rows are allocated.  Rows are
+ *             interleaved within every group of 32 output channels: stored row 16h + 4q + r holds
+ *             output channel 8q + 4h + r (h in 0..1, q, r in 0..3), so that a lane of the MFMA result
+ *             owns 8 consecutive output channels (16-byte stores straight from the accumulators)
  *   bias      [C_out] float32 (NULL = none)
  *   residual  same addressing as out with res_* fields; when H_res/W_res differ from
  *             H_out/W_out the residual is read with TF nearest-neighbour resize semantics
  *             src = min(floor(dst * in/out), in-1)  (tf.image.resize_images, align_corners=False)
  *   out       element type = dtype, or float32 when out_f32 != 0
- *   zero_page >= 256 bytes of zeros (source of out-of-image taps)
+ *   zero_page unused since v0.2 (padding comes from range-checked buffer loads); may be NULL
  * Requirements: C_in % 64 == 0; C_out % 4 == 0; in_pitch, out_pitch, res_pitch multiples of 8
  * (4 for float32 out); all base pointers 16-byte aligned; stride in {1, 2}.
  * Padding is explicit (pad_top, pad_left); bottom/right padding is implied by H_out/W_out
  * (this covers Keras 'same' at stride 1, TF's asymmetric 'same' at stride 2, and
- * ZeroPadding2D + 'valid').
+ * ZeroPadding2D + 'valid').  Every input map and the weight tensor must be smaller than 2 GiB.
  * ---------------------------------------------------------------------------------------- */
 #define GPP_MAX_GROUPS 5
 
@@ -128,6 +131,9 @@ typedef struct gpp_conv_desc {
     int32_t weight_rows;
     int32_t relu;
     int32_t n_groups;
+    int32_t tile_hint;              /* 0 = library chooses the tile; 128 / 256 force the block-tile height (tuning, tests) */
+    int32_t reserved;
+    int32_t in_bytes, weight_bytes; /* filled in by the library: extents for the range-checked buffer loads */
     gpp_conv_group groups[GPP_MAX_GROUPS];
 } gpp_conv_desc;
 

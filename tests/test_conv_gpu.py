@@ -52,9 +52,10 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize('tile', [128, 256, 512])
 @pytest.mark.parametrize('dtype', ['bf16', 'f16'])
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
-def test_conv_matches_torch_fp32(case, dtype):
+def test_conv_matches_torch_fp32(case, dtype, tile):
     name, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, out_f32 = case
     g = torch.Generator().manual_seed(sum(map(ord, name)))
     tdt = C.torch_dtype(dtype)
@@ -81,7 +82,7 @@ def test_conv_matches_torch_fp32(case, dtype):
     w = C.pack_weight(k.float().numpy(), dtype, dev)
     rmap = None if res is None else [C.FMap(res.to(dev).contiguous(), B, res.shape[1], res.shape[2], Cout)]
     d = C.conv_desc([xin], [out], w, bias.to(dev), K, K, Cin, Cout, stride=stride, pad=(pt, pl), relu=relu,
-                    residuals=rmap, dtype=dtype, out_f32=out_f32)
+                    residuals=rmap, dtype=dtype, out_f32=out_f32, tile_hint=tile)
     C.run_conv(d)
     got = out.buf.float().cpu()
     assert torch.isfinite(got).all()
@@ -92,7 +93,8 @@ def test_conv_matches_torch_fp32(case, dtype):
     assert abs(C.conv_flops(d) - 2.0 * B * oh * ow * K * K * Cin * Cout) < 1.0
 
 
-def test_grouped_pyramid_launch_and_channel_slices():
+@pytest.mark.parametrize('tile', [128, 256])
+def test_grouped_pyramid_launch_and_channel_slices(tile):
     """ five feature maps of different sizes in one launch, inputs read as a channel slice of a
     wider tensor, outputs written at level offsets of one (B, sum(HW), C) pyramid tensor """
     dev = torch.device('cuda')
@@ -111,7 +113,7 @@ def test_grouped_pyramid_launch_and_channel_slices():
         outs.append(C.FMap(od, B, h, w, Cout, off=off * Cout, bstride=total * Cout))
         off += h * w
     d = C.conv_desc(ins, outs, C.pack_weight(k.float().numpy(), 'bf16', dev), bias.to(dev), 3, 3, Cin, Cout,
-                    pad=(1, 1), relu=True)
+                    pad=(1, 1), relu=True, tile_hint=tile)
     C.run_conv(d)
     got = od.float().cpu()
     off = 0

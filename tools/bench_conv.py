@@ -12,7 +12,7 @@ from keras_retinanet_3D.layers import conv as C  # noqa: E402
 PYR = [(51, 167), (26, 84), (13, 42), (7, 21), (4, 11)]
 
 
-def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False):
+def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False, tile=0, diag=0):
     dev = torch.device('cuda')
     tdt = C.torch_dtype(dtype)
     total = sum(h * w for h, w in shapes)
@@ -25,7 +25,7 @@ def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False):
         ins.append(C.FMap(x, B, h, wd, Cin, off=off * Cin, bstride=total * Cin))
         outs.append(C.FMap(o, B, h, wd, Cout, off=off * Cout, bstride=total * Cout))
         off += h * wd
-    d = C.conv_desc(ins, outs, w, bias, K, K, Cin, Cout, pad=(K // 2, K // 2), relu=True, dtype=dtype, out_f32=out_f32)
+    d = C.conv_desc(ins, outs, w, bias, K, K, Cin, Cout, pad=(K // 2, K // 2), relu=True, dtype=dtype, out_f32=out_f32, tile_hint=tile, diag=diag)
     for _ in range(3):
         C.run_conv(d)
     torch.cuda.synchronize()
@@ -43,7 +43,20 @@ def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False):
 
 if __name__ == '__main__':
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    bench('reg tower 3x3 512->512', B, PYR, 512, 512, 3)
+    if len(sys.argv) > 2 and sys.argv[2] == 'ablate':
+        for tile in (128, 256, 512):
+            for diag, what in ((0, 'full'), (1, 'no LDS-DMA (compute only)'), (2, 'no LDS reads/MFMA (loads only)'), (3, 'neither')):
+                bench('reg 3x3 512 t%d %s' % (tile, what), B, PYR, 512, 512, 3, tile=tile, diag=diag)
+        sys.exit(0)
+    bench('reg tower 3x3 512->512 t128', B, PYR, 512, 512, 3, tile=128)
+    bench('reg tower 3x3 512->512 t256', B, PYR, 512, 512, 3, tile=256)
+    bench('reg tower 3x3 512->512 t512', B, PYR, 512, 512, 3, tile=512)
+    bench('P3 3x3 512->512 t512', B, PYR[:1], 512, 512, 3, tile=512)
+    bench('cls tower 3x3 256->256 t512', B, PYR, 256, 256, 3, tile=512)
+    bench('cls tower 3x3 256->256 t256', B, PYR, 256, 256, 3, tile=256)
+    bench('P3 3x3 512->512 t256', B, PYR[:1], 512, 512, 3, tile=256)
+    bench('cls0 3x3 512->256 t256', B, PYR, 512, 256, 3, tile=256)
+    bench('cls0 3x3 512->256 t128', B, PYR, 512, 256, 3, tile=128)
     bench('cls tower 3x3 256->256', B, PYR, 256, 256, 3)
     bench('dim tower 3x3 128->128', B, PYR, 128, 128, 3)
     bench('reg out 3x3 512->144 f32', B, PYR, 512, 144, 3, out_f32=True)
