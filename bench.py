@@ -191,7 +191,7 @@ def main():
                        'achieved_tflops_whole_path': round(plan.flops * args.steps / elapsed / 1e12, 1)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': None,
-                         'kernel': 'conv_igemm_kernel<{},128,128> on pyramid_regression_0..3 (3x3, 512->512, 5 levels, M={})'.format(
+                         'kernel': 'conv_igemm_kernel<{},256,256,2,4,2> on pyramid_regression_0..3 (3x3, 512->512, 5 levels, M={})'.format(
                              args.dtype, B * (plan.n_anchors // 12)),
                          'gflop_per_launch': round(flops_per_launch / 1e9, 1), 'mean_launch_ms': round(mean_ms, 4),
                          'launches_timed': len(durations)},

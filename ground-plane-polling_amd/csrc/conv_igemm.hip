@@ -75,6 +75,69 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
+// Finish 8 consecutive output channels of one output pixel: (+ residual through the optional TF
+// nearest resize) (+ ReLU), convert, store.  v already holds accumulator + bias.
+template <int DT>
+__device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], int n, int64_t obase,
+                                        const typename Elem<DT>::scalar* rrow)
+{
+    using vec8 = typename Elem<DT>::vec8;
+    using scalar = typename Elem<DT>::scalar;
+    const bool full = (n + 8 <= d.C_out);
+    if (rrow) {
+        if (full) {
+            const vec8 rv = *(const vec8*)(rrow + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        } else {
+            for (int e = 0; e < 8 && n + e < d.C_out; ++e) v[e] += (float)rrow[n + e];
+        }
+    }
+    if (d.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+    }
+    if (d.out_f32) {
+        float* dst = (float*)d.out + obase + n;
+        if (full) {
+            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        } else {
+            for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = v[e];
+        }
+    } else {
+        scalar* dst = (scalar*)d.out + obase + n;
+        if (full) {
+            vec8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (scalar)v[e];
+            *(vec8*)dst = ov;
+        } else {
+            for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = (scalar)v[e];
+        }
+    }
+}
+
+// Where output row m of a group lives (and its residual row).
+struct RowAddr { int64_t obase; int64_t rbase; };
+__device__ __forceinline__ RowAddr row_addr(const gpp_conv_desc& d, int m, int HoWo, int W_out, int H_out, int H_res, int W_res,
+                                            int64_t out_off, int64_t out_bs, int64_t res_off, int64_t res_bs)
+{
+    const int b = m / HoWo, p = m - b * HoWo;
+    int64_t rp = p;
+    if (d.residual && (H_res != H_out || W_res != W_out)) {
+        const float sy = (float)H_res / (float)H_out, sx = (float)W_res / (float)W_out;
+        const int oy = p / W_out, ox = p - oy * W_out;
+        const int ry = min((int)floorf((float)oy * sy), H_res - 1);
+        const int rx = min((int)floorf((float)ox * sx), W_res - 1);
+        rp = (int64_t)ry * W_res + rx;
+    }
+    RowAddr a;
+    a.obase = out_off + (int64_t)b * out_bs + (int64_t)p * d.out_pitch;
+    a.rbase = res_off + (int64_t)b * res_bs + rp * d.res_pitch;
+    return a;
+}
+
 template <int DT, int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_conv_desc d)
 {
@@ -118,7 +181,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     const int m0 = (mt - tile_start) * BM, n0 = nt * BN;
     const int Ktot = d.KH * d.KW * d.C_in;
     const int cpt = d.C_in >> 6;                        // 64-channel chunks per tap
-    const int nk = d.KH * d.KW * cpt;
+    const int nk_total = d.KH * d.KW * cpt;
+    // split-K: blockIdx.y owns K-steps [ks0, ks0 + nk); partial sums go to d.partial, the epilogue runs
+    // in splitk_reduce_kernel
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int ks0 = (int)((int64_t)nk_total * split / nsplit);
+    const int nk = (int)((int64_t)nk_total * (split + 1) / nsplit) - ks0;
 
     // ---- staging bookkeeping: this lane owns LDS chunk (row srow of each 8-row piece, slot lane&7)
     // and fetches source chunk gchunk = slot ^ srow (inverse of the read swizzle).  Byte offsets are
@@ -186,10 +254,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     // stage ks only (later stages stay in flight across the barrier); after the barrier every
     // wave's loads of stage ks have landed and every wave has finished reading the buffer of step
     // ks-1, which is exactly the buffer the next prefetch (stage ks+PF) overwrites.
-    int kh = 0, kw = 0, cc = 0, issued = 0, ibuf = 0;
-    set_tap(0, 0);
+    int cc = ks0 % cpt, kw = (ks0 / cpt) % d.KW, kh = (ks0 / cpt) / d.KW, issued = 0, ibuf = 0;
+    set_tap(kh, kw);
     auto issue_next = [&]() {
-        stage(ibuf, cc, issued);
+        stage(ibuf, cc, ks0 + issued);
         if (++cc == cpt) {
             cc = 0;
             if (++kw == d.KW) { kw = 0; ++kh; }
@@ -237,10 +305,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     // one 16-byte store (two for float32 output), no LDS round trip.
     constexpr int COLS = BN / WN;                        // output channels owned by this wave
     static_assert(NF % 2 == 0, "N tiles come in interleaved pairs");
+    if (nsplit > 1) {
+        // raw float32 partial tile -> d.partial[split][mt*BM + row][nt*BN + col]
+        const int64_t rows_pad = (int64_t)d.partial_rows, npad = (int64_t)n_tiles * BN;
+        float* part = (float*)d.partial + ((int64_t)split * rows_pad + (int64_t)mt * BM) * npad + nt * BN;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int lr = wm * (BM / WM) + i * 16 + frow;
+#pragma unroll
+            for (int jj = 0; jj < NF / 2; ++jj) {
+                float* dst = part + (int64_t)lr * npad + wn * COLS + jj * 32 + fq * 8;
+                *(f32x4*)dst = acc[i][2 * jj];
+                *(f32x4*)(dst + 4) = acc[i][2 * jj + 1];
+            }
+        }
+        return;
+    }
     const scalar* res = (const scalar*)d.residual;
-    const bool resize = (H_res != H_out) || (W_res != W_out);
-    const float sy = resize ? (float)H_res / (float)H_out : 1.0f;
-    const float sx = resize ? (float)W_res / (float)W_out : 1.0f;
     float bias_v[NF / 2][8];
 #pragma unroll
     for (int jj = 0; jj < NF / 2; ++jj) {
@@ -252,61 +333,66 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     for (int i = 0; i < MF; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + frow;
         if (m >= Mg) continue;
-        const int b = m / HoWo, p = m - b * HoWo;
-        int64_t rp = p;
-        if (res && resize) {
-            const int oy = p / W_out, ox = p - oy * W_out;
-            const int ry = min((int)floorf((float)oy * sy), H_res - 1);
-            const int rx = min((int)floorf((float)ox * sx), W_res - 1);
-            rp = (int64_t)ry * W_res + rx;
-        }
-        const int64_t obase = out_off + (int64_t)b * out_bs + (int64_t)p * d.out_pitch;
-        const scalar* rrow = res ? res + res_off + (int64_t)b * res_bs + rp * d.res_pitch : nullptr;
+        const RowAddr ra = row_addr(d, m, HoWo, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
+        const scalar* rrow = res ? res + ra.rbase : nullptr;
 #pragma unroll
         for (int jj = 0; jj < NF / 2; ++jj) {
             const int n = n0 + wn * COLS + jj * 32 + fq * 8;
             if (n >= d.C_out) continue;
-            const bool full = (n + 8 <= d.C_out);
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
                 v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
             }
-            if (rrow) {
-                if (full) {
-                    const vec8 rv = *(const vec8*)(rrow + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-                } else {
-                    for (int e = 0; e < 8 && n + e < d.C_out; ++e) v[e] += (float)rrow[n + e];
-                }
-            }
-            if (d.relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-            }
-            if (d.out_f32) {
-                float* dst = (float*)d.out + obase + n;
-                if (full) {
-                    *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                } else {
-                    for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = v[e];
-                }
-            } else {
-                scalar* dst = (scalar*)d.out + obase + n;
-                if (full) {
-                    vec8 ov;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ov[e] = (scalar)v[e];
-                    *(vec8*)dst = ov;
-                } else {
-                    for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = (scalar)v[e];
-                }
-            }
+            finish8<DT>(d, v, n, ra.obase, rrow);
         }
     }
+}
+
+// Second pass of a split-K launch: sum the partial slabs in split order (deterministic), then the
+// same epilogue as the fused path.  One thread per (output row, 8 output channels).
+template <int DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const gpp_conv_desc d, int BM, int npad, int nsplit)
+{
+    using scalar = typename Elem<DT>::scalar;
+    const int n8 = (d.C_out + 7) / 8;
+    const int64_t total = (int64_t)d.partial_rows * n8;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int r = (int)(e / n8), n = (int)(e - (int64_t)r * n8) * 8;
+    const int mt = r / BM;
+    int tile_start = 0, H_out = 0, W_out = 0, H_res = 0, W_res = 0;
+    int64_t out_off = 0, out_bs = 0, res_off = 0, res_bs = 0;
+#pragma unroll
+    for (int q = 0; q < GPP_MAX_GROUPS; ++q) {
+        if (q < d.n_groups && mt >= d.groups[q].tile_start) {
+            tile_start = d.groups[q].tile_start;
+            H_out = d.groups[q].H_out; W_out = d.groups[q].W_out;
+            H_res = d.groups[q].H_res; W_res = d.groups[q].W_res;
+            out_off = d.groups[q].out_off; out_bs = d.groups[q].out_bstride;
+            res_off = d.groups[q].res_off; res_bs = d.groups[q].res_bstride;
+        }
+    }
+    const int HoWo = H_out * W_out;
+    const int m = r - tile_start * BM;
+    if (m >= d.batch * HoWo) return;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.0f;
+    const float* src = (const float*)d.partial + (int64_t)r * npad + n;
+    for (int s = 0; s < nsplit; ++s) {
+        const f32x4 a = *(const f32x4*)(src + (int64_t)s * d.partial_rows * npad);
+        const f32x4 b = *(const f32x4*)(src + (int64_t)s * d.partial_rows * npad + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+    }
+    if (d.bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (n + k < d.C_out) v[k] += d.bias[n + k];
+    }
+    const RowAddr ra = row_addr(d, m, HoWo, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
+    finish8<DT>(d, v, n, ra.obase, d.residual ? (const scalar*)d.residual + ra.rbase : nullptr);
 }
 
 // One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.
@@ -339,7 +425,24 @@ int launch(gpp_conv_desc& d, hipStream_t st)
         tiles += (d.batch * d.groups[g].H_out * d.groups[g].W_out + BM - 1) / BM;
     }
     const int n_tiles = (d.C_out + BN - 1) / BN;
-    kernel<<<dim3((unsigned)(tiles * n_tiles)), dim3(64 * WM * WN), lds, st>>>(d);
+    // split-K when the tile grid leaves most of the 256 CUs idle and K is deep: every split keeps
+    // >= 8 K-steps; partial slabs [split][tiles*BM][n_tiles*BN] float32 must fit the workspace
+    const int nk = d.KH * d.KW * (d.C_in / 64);
+    int nsplit = 1;
+    if (d.partial && d.split_k != 1) {
+        const int blocks = tiles * n_tiles;
+        int want = d.split_k > 1 ? d.split_k : (blocks < 192 ? (384 + blocks - 1) / blocks : 1);
+        while (want > 1 && nk / want < 8) --want;
+        const int64_t slab = (int64_t)tiles * BM * n_tiles * BN * 4;
+        while (want > 1 && slab * want > (int64_t)d.partial_bytes) --want;
+        nsplit = want < 1 ? 1 : want;
+    }
+    d.partial_rows = tiles * BM;
+    kernel<<<dim3((unsigned)(tiles * n_tiles), (unsigned)nsplit), dim3(64 * WM * WN), lds, st>>>(d);
+    if (nsplit > 1) {
+        const int64_t total = (int64_t)d.partial_rows * ((d.C_out + 7) / 8);
+        splitk_reduce_kernel<DT><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(d, BM, n_tiles * BN, nsplit);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }

@@ -62,6 +62,7 @@ class ConvDesc(ctypes.Structure):
                 ('weight_rows', ctypes.c_int32), ('relu', ctypes.c_int32), ('n_groups', ctypes.c_int32),
                 ('tile_hint', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('in_bytes', ctypes.c_int32), ('weight_bytes', ctypes.c_int32),
+                ('partial', c_void_p), ('partial_bytes', c_int64), ('split_k', ctypes.c_int32), ('partial_rows', ctypes.c_int32),
                 ('groups', ConvGroup * GPP_MAX_GROUPS)]
 
 

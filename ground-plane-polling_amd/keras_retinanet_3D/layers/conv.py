@@ -89,7 +89,8 @@ def same_pad(in_size, k, stride):
 
 
 def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=(0, 0), relu=False,
-              residuals=None, dtype='bf16', out_f32=False, tile_hint=0, diag=0):
+              residuals=None, dtype='bf16', out_f32=False, tile_hint=0, diag=0,
+              workspace=None, split_k=0):
     """ Build a gpp_conv_desc.  inputs / outputs / residuals are lists of FMap (one per group,
     all groups share weights; every list member must live in the same torch buffer). """
     d = hip.ConvDesc()
@@ -112,6 +113,10 @@ def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=
     d.n_groups = len(inputs)
     d.tile_hint = int(tile_hint)
     d.reserved = int(diag)          # diagnostic ablation bits (timing experiments only)
+    if workspace is not None:       # split-K partial tiles (float32); the library decides whether to split
+        d.partial = workspace.data_ptr()
+        d.partial_bytes = workspace.numel() * workspace.element_size()
+    d.split_k = int(split_k)
     assert 1 <= len(inputs) <= hip.GPP_MAX_GROUPS and len(outputs) == len(inputs)
     assert int(weight.shape[1]) == KH * KW * C_in
     for g, (fi, fo) in enumerate(zip(inputs, outputs)):

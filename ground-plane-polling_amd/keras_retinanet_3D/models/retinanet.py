@@ -158,13 +158,15 @@ class RetinaNet3D(object):
         if pad is None:
             pad = (0, 0)
         d = C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
-                        residuals=residuals, dtype=self.dtype, out_f32=out_f32)
+                        residuals=residuals, dtype=self.dtype, out_f32=out_f32, workspace=plan.workspace)
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d))
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
         torch, dev, dt = self.torch, self.device, self.tdtype
         plan = Plan()
         plan.shape = (B, H, Wd, n_planes, planes_batched)
+        # split-K partial tiles of the under-filled deep-K layers (res5, P5..P7); reused by every launch
+        plan.workspace = torch.empty((64 << 20,), dtype=torch.uint8, device=dev)
 
         def fmap(h, w, c, dtype=None):
             f = C.FMap.empty(B, h, w, c, dtype or dt, dev)

@@ -134,6 +134,10 @@ typedef struct gpp_conv_desc {
     int32_t tile_hint;              /* 0 = library chooses the tile; 128 / 256 force the block-tile height (tuning, tests) */
     int32_t reserved;
     int32_t in_bytes, weight_bytes; /* filled in by the library: extents for the range-checked buffer loads */
+    void* partial;                  /* optional split-K workspace (float32 partial tiles), 16-byte aligned; NULL = never split */
+    int64_t partial_bytes;
+    int32_t split_k;                /* 0 = library decides, 1 = never, k > 1 = force k splits (tests) */
+    int32_t partial_rows;           /* filled in by the library */
     gpp_conv_group groups[GPP_MAX_GROUPS];
 } gpp_conv_desc;
 

@@ -134,3 +134,37 @@ def test_conv_rejects_bad_descriptors():
     d = C.conv_desc([x], [o], w, None, 1, 1, 48, 64)
     with pytest.raises(hip.GppError):
         C.run_conv(d)
+
+
+@pytest.mark.parametrize('split', [0, 2, 3, 8])
+@pytest.mark.parametrize('case', ['P6_like', 'res5_like', 'f32_out_resid'])
+def test_split_k_matches_torch_fp32(case, split):
+    """ deep-K, small-M layers: K range split over blockIdx.y, float32 partial tiles, second-pass reduce """
+    B, H, W, Cin, Cout, K, stride, relu, out_f32, with_res = {
+        'P6_like': (2, 13, 42, 512, 512, 3, 2, False, False, False),
+        'res5_like': (1, 13, 21, 512, 256, 3, 1, True, False, True),
+        'f32_out_resid': (1, 9, 11, 1024, 36, 1, 1, False, True, False),
+    }[case]
+    g = torch.Generator().manual_seed(7)
+    dev = torch.device('cuda')
+    x = torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16)
+    k = (torch.randn((K, K, Cin, Cout), generator=g) * (2.0 / (K * K * Cin)) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    oh, pt = C.same_pad(H, K, stride)
+    ow, pl = C.same_pad(W, K, stride)
+    res = torch.randn((B, oh, ow, Cout), generator=g).to(torch.bfloat16) if with_res else None
+    ref = reference(x.float(), k.float(), bias, stride, pt, pl, oh, ow, relu, None if res is None else res.float())
+    xin = C.FMap(x.to(dev).contiguous(), B, H, W, Cin)
+    out = C.FMap.empty(B, oh, ow, Cout, torch.float32 if out_f32 else torch.bfloat16, dev)
+    out.buf.fill_(float('nan'))
+    ws = torch.empty((32 << 20,), dtype=torch.uint8, device=dev)
+    rmap = None if res is None else [C.FMap(res.to(dev).contiguous(), B, oh, ow, Cout)]
+    d = C.conv_desc([xin], [out], C.pack_weight(k.float().numpy(), 'bf16', dev), bias.to(dev), K, K, Cin, Cout, stride=stride,
+                    pad=(pt, pl), relu=relu, residuals=rmap, out_f32=out_f32, workspace=ws, split_k=split)
+    C.run_conv(d)
+    got = out.buf.float().cpu()
+    eps = 1e-4 if out_f32 else 2.0 ** -8
+    err = (got - ref).abs()
+    assert bool((err <= eps * ref.abs() + 1e-3).all()), err.max().item()
+    C.run_conv(d)                                              # deterministic: fixed summation order over the splits
+    assert torch.equal(out.buf.float().cpu(), got)
