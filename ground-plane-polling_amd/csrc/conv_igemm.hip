@@ -138,7 +138,7 @@ __device__ __forceinline__ RowAddr row_addr(const gpp_conv_desc& d, int m, int H
     return a;
 }
 
-template <int DT, int BM, int BN, int WM, int WN, int STAGES>
+template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_conv_desc d)
 {
     using E = Elem<DT>;
@@ -266,6 +266,99 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
         ++issued;
         if (++ibuf == STAGES) ibuf = 0;
     };
+    auto load_frags = [&](vec8 (&af)[MF], vec8 (&bfr)[NF], int buf, int kk) {
+        const unsigned char* sbase = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af[i] = *(const vec8*)(sbase + a_rd[kk] + i * 16 * kRowBytes);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) bfr[j] = *(const vec8*)(sbase + b_rd[kk] + j * 16 * kRowBytes);
+    };
+    auto mfma_all = [&](const vec8 (&af)[MF], const vec8 (&bfr)[NF]) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = E::mfma(bfr[j], af[i], acc[i][j]);
+    };
+
+    if constexpr (PIPE) {
+        // Software-pipelined, explicitly interleaved form (two LDS buffers).  Per K-step k:
+        //   phase 0:  MFMA(kk=0 of k)  ||  LDS reads of kk=1 of k
+        //   wait stage k+1 landed, lgkmcnt(0), s_barrier      (everyone is done reading buffer k&1)
+        //   phase 1:  MFMA(kk=1 of k)  ||  LDS-DMA of stage k+2 into buffer k&1  ||  LDS reads of kk=0 of k+1
+        // Each phase is cut into MF groups {1-2 LDS-DMA, 1-2 ds_read_b128, NF MFMA} pinned with
+        // sched_barrier, so the ~100-cycle issue cost of every LDS-DMA and the LDS read latency sit
+        // under matrix-pipe work instead of in front of it.  In the tail the DMA goes through a
+        // zero-length descriptor (dropped by the range check) and the look-ahead reads hit a buffer
+        // nobody uses: no branches inside the interleaved region.
+        static_assert(STAGES == 2 && PER_STAGE % MF == 0, "pipelined loop: two buffers, loads divide over the groups");
+        constexpr int LPG = PER_STAGE / MF;              // LDS-DMA instructions per group
+        const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, 0, 0x00020000);
+        auto issue_one = [&](int idx, int buf, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int so_a, int so_w) {
+            unsigned char* sa = smem + buf * STAGE + wave * A_IT * 8 * kRowBytes;
+            unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
+            if (idx < A_IT) glds16(ra, a_voff[idx < A_IT ? idx : 0], so_a, sa + idx * 8 * kRowBytes);
+            else glds16(rw, w_voff[idx >= A_IT ? idx - A_IT : 0], so_w, sb + (idx - A_IT) * 8 * kRowBytes);
+        };
+        auto advance_tap = [&]() {
+            if (++cc == cpt) {
+                cc = 0;
+                if (++kw == d.KW) { kw = 0; ++kh; }
+                set_tap(kh, kw);
+            }
+            ++issued;
+        };
+        vec8 a0[MF], b0[NF], a1[MF], b1[NF];
+        // prologue: stage 0 -> buffer 0, wait, stage 1 -> buffer 1, fragments kk=0 of step 0
+#pragma unroll
+        for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 0, in_rsrc, w_rsrc, cc * kRowBytes, ks0 * kRowBytes);
+        advance_tap();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const bool live = issued < nk;
+            const __amdgpu_buffer_rsrc_t ra = live ? in_rsrc : null_rsrc, rw = live ? w_rsrc : null_rsrc;
+#pragma unroll
+            for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 1, ra, rw, cc * kRowBytes, (ks0 + issued) * kRowBytes);
+            if (live) advance_tap();
+        }
+        load_frags(a0, b0, 0, 0);
+        for (int ks = 0; ks < nk; ++ks) {
+            const int cur = ks & 1;
+            const unsigned char* scur = smem + cur * STAGE;
+            const unsigned char* snxt = smem + (cur ^ 1) * STAGE;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase 0
+#pragma unroll
+            for (int g = 0; g < MF; ++g) {
+                a1[g] = *(const vec8*)(scur + a_rd[1] + g * 16 * kRowBytes);
+                if (g < NF) b1[g < NF ? g : 0] = *(const vec8*)(scur + b_rd[1] + g * 16 * kRowBytes);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[g][j] = E::mfma(b0[j], a0[g], acc[g][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool live = issued < nk;
+            const __amdgpu_buffer_rsrc_t ra = live ? in_rsrc : null_rsrc, rw = live ? w_rsrc : null_rsrc;
+            const int so_a = cc * kRowBytes, so_w = (ks0 + issued) * kRowBytes;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase 1
+#pragma unroll
+            for (int g = 0; g < MF; ++g) {
+#pragma unroll
+                for (int q = 0; q < LPG; ++q) issue_one(g * LPG + q, cur, ra, rw, so_a, so_w);
+                a0[g] = *(const vec8*)(snxt + a_rd[0] + g * 16 * kRowBytes);
+                if (g < NF) b0[g < NF ? g : 0] = *(const vec8*)(snxt + b_rd[0] + g * 16 * kRowBytes);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[g][j] = E::mfma(b1[j], a1[g], acc[g][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (live) advance_tap();         // a_voff for the next issue changes only after this step's DMA is out
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < PF; ++p)
         if (issued < nk) issue_next();
@@ -281,21 +374,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
         if (issued < nk) {
             if (d.reserved & 1) { ++issued; } else issue_next();      // bit 0 (diagnostic): skip the LDS-DMA
         }
-        const unsigned char* sbase = smem + cbuf * STAGE;
-        if (!(d.reserved & 2))                                         // bit 1 (diagnostic): skip LDS reads + MFMA
+        if (!(d.reserved & 2)) {                                       // bit 1 (diagnostic): skip LDS reads + MFMA
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            vec8 af[MF], bfr[NF];
-#pragma unroll
-            for (int i = 0; i < MF; ++i) af[i] = *(const vec8*)(sbase + a_rd[kk] + i * 16 * kRowBytes);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) bfr[j] = *(const vec8*)(sbase + b_rd[kk] + j * 16 * kRowBytes);
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = E::mfma(bfr[j], af[i], acc[i][j]);
+            for (int kk = 0; kk < 2; ++kk) {
+                vec8 af[MF], bfr[NF];
+                load_frags(af, bfr, cbuf, kk);
+                mfma_all(af, bfr);
+            }
         }
         if (++cbuf == STAGES) cbuf = 0;
+    }
     }
     // ---- epilogue, straight from registers.  The MFMA was issued as D = W_tile * X_tile^T, so
     // lane (fq = lane>>4, c = lane&15) of accumulator (i, j) holds output pixel i*16 + c and the four
@@ -396,12 +484,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const gpp_conv_desc 
 }
 
 // One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.
-template <int DT, int BM, int BN, int WM, int WN, int STAGES>
+template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
 int launch(gpp_conv_desc& d, hipStream_t st)
 {
     constexpr int lds = STAGES * (BM + BN) * kRowBytes;
     static bool configured = false;
-    auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES>;
+    auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES, PIPE>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
@@ -454,15 +542,15 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
     int64_t rows = 0;
     for (int g = 0; g < d.n_groups; ++g) rows += (int64_t)d.batch * d.groups[g].H_out * d.groups[g].W_out;
     const int nk = d.KH * d.KW * (d.C_in / 64);
-    if (narrow) return launch<DT, 128, 64, 2, 2, 2>(d, st);
+    if (narrow) return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
     // 256x256 tile (8 wavefronts, 1 workgroup / CU) halves the L2 -> LDS traffic per FLOP; it pays
     // when there are enough tiles for two rounds over the 256 CUs and enough K-steps to amortise
     // its longer prologue/epilogue.  (256x128 with a 3-deep ring is kept for experiments only.)
     const int64_t big_blocks = ((rows + 255) / 256) * (d.C_out / 256);
     if (d.tile_hint == 512 || (d.tile_hint == 0 && d.C_out % 256 == 0 && big_blocks >= 512 && nk >= 8))
-        return launch<DT, 256, 256, 2, 4, 2>(d, st);
-    if (d.tile_hint == 256) return launch<DT, 256, 128, 4, 2, 3>(d, st);
-    return launch<DT, 128, 128, 2, 2, 2>(d, st);
+        return (d.reserved & 8) ? launch<DT, 256, 256, 2, 4, 2, false>(d, st) : launch<DT, 256, 256, 2, 4, 2, true>(d, st);
+    if (d.tile_hint == 256) return launch<DT, 256, 128, 4, 2, 3, false>(d, st);
+    return (d.reserved & 4) ? launch<DT, 128, 128, 2, 2, 2, true>(d, st) : launch<DT, 128, 128, 2, 2, 2, false>(d, st);
 }
 
 int validate(const gpp_conv_desc& d)

@@ -43,6 +43,14 @@ def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False, 
 
 if __name__ == '__main__':
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    if len(sys.argv) > 2 and sys.argv[2] == 'pipe':
+        for rep in range(2):
+            for tile in (128, 512):
+                for diag, what in ((0, 'plain'), (4, 'pipelined')):
+                    bench('reg 3x3 512 t%d %s' % (tile, what), B, PYR, 512, 512, 3, tile=tile, diag=diag)
+            bench('cls 3x3 256 t128 plain', B, PYR, 256, 256, 3, tile=128, diag=0)
+            bench('cls 3x3 256 t128 pipelined', B, PYR, 256, 256, 3, tile=128, diag=4)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'ablate':
         for tile in (128, 256, 512):
             for diag, what in ((0, 'full'), (1, 'no LDS-DMA (compute only)'), (2, 'no LDS reads/MFMA (loads only)'), (3, 'neither')):
