@@ -22,7 +22,7 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
         switch (op.kind) {
         case GPP_OP_STEM: {
             const gpp_stem_desc* d = (const gpp_stem_desc*)op.desc;
-            rc = gpp_stem_conv7x7_bn_relu(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
+            rc = gpp_stem_conv7x7_bn_relu_mfma(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
             break;
         }
         case GPP_OP_MAXPOOL: {

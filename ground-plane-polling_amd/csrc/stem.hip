@@ -76,6 +76,105 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
     }
 }
 
+// ---- MFMA version ---------------------------------------------------------------------------------
+// GEMM view per output row segment: D[n][px] = sum_k W[n][k] * X[k][px], k = (kh, kw*3 + c) with the 21
+// taps of one kernel row padded to 32 (weights zero there), i.e. K = 7 * 32 = 224.  The pixel operand
+// of output pixel ox for kernel row kh is the 32 CONSECUTIVE f16 values that start at element 6*ox of
+// input row 2*oy + kh - 3 in the staged patch (stride-2 conv over 3 interleaved channels): no im2col.
+// Input and weights are rounded to f16 (11-bit significand; |x| <= 152 so the step is <= 2^-4) and
+// accumulated in float32 by v_mfma_f32_16x16x32_f16, whatever the activation type of the network.
+// Weights [64 rows interleaved as for conv_igemm][7][32] f16 stay in LDS for the life of the
+// (persistent) workgroup; each wavefront owns one output row of 64 pixels x 64 channels.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+constexpr int MW_PITCH = 232;                   // halfs per weight row in LDS (224 + 8: conflict-free b128 reads)
+constexpr int MP_PX = TW * 2 + 9;               // patch pixels per row: 2*63 + 32/3 rounded up
+constexpr int MP_PITCH = 416;                   // halfs per patch row (>= 3 * MP_PX = 411)
+constexpr int MP_ROWS = TH * 2 + 5;
+
+template <typename scalar, typename vec8>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in, const _Float16* __restrict__ w,
+                                                        const float* __restrict__ bias, scalar* __restrict__ out,
+                                                        int B, int H, int W, int Ho, int Wo)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[64 * MW_PITCH];
+    __shared__ __attribute__((aligned(16))) _Float16 s_p[MP_ROWS * MP_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 64 * MW_PITCH / 8; e += 256) ((uint4*)s_w)[e] = ((const uint4*)w)[e];
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y * B;
+    const int frow = lane & 15, fq = lane >> 4;
+    float bias_v[2][8];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias_v[jj][e] = bias[jj * 32 + fq * 8 + e];
+
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int b = t / (tiles_x * tiles_y), r = t - b * (tiles_x * tiles_y);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int ox0 = tx * TW, oy0 = ty * TH;
+        const int ix0 = ox0 * 2 - 3, iy0 = oy0 * 2 - 3;
+        const float* img = in + (size_t)b * H * W * 3;
+        __syncthreads();                                     // previous tile's readers are done with s_p
+        for (int e = tid; e < MP_ROWS * (MP_PITCH / 2); e += 256) {
+            const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
+            const int iy = iy0 + pr;
+            float v0 = 0.0f, v1 = 0.0f;
+            if ((unsigned)iy < (unsigned)H) {
+                const int x0 = ix0 * 3 + c2;                 // element index inside the image row
+                const float* rowp = img + (size_t)iy * W * 3;
+                if (x0 >= 0 && x0 < W * 3) v0 = rowp[x0];
+                if (x0 + 1 >= 0 && x0 + 1 < W * 3) v1 = rowp[x0 + 1];
+            }
+            *(f16x2*)(s_p + pr * MP_PITCH + c2) = (f16x2){(_Float16)v0, (_Float16)v1};
+        }
+        __syncthreads();
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            f16x8 wf[4], xf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *(const f16x8*)(s_w + (j * 16 + frow) * MW_PITCH + kh * 32 + fq * 8);
+            const _Float16* prow = s_p + (wave * 2 + kh) * MP_PITCH + fq * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x2* src = (const f16x2*)(prow + (i * 16 + frow) * 6);
+                const f16x2 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+                xf[i] = (f16x8){p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+        const int oy = oy0 + wave;
+        if (oy < Ho) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ox = ox0 + i * 16 + frow;
+                if (ox >= Wo) continue;
+                scalar* dst = out + (((size_t)b * Ho + oy) * Wo + ox) * 64;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    vec8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (scalar)fmaxf(acc[i][2 * jj][e] + bias_v[jj][e], 0.0f);
+                        v[4 + e] = (scalar)fmaxf(acc[i][2 * jj + 1][e] + bias_v[jj][4 + e], 0.0f);
+                    }
+                    *(vec8*)(dst + jj * 32 + fq * 8) = v;
+                }
+            }
+        }
+    }
+}
+
 // 3x3 stride-2 max-pool, TF 'same' (pad_before = pad_total / 2, padding never wins)
 template <typename scalar, typename vec8>
 __global__ __launch_bounds__(256) void maxpool_kernel(const scalar* __restrict__ in, scalar* __restrict__ out,
@@ -146,6 +245,43 @@ extern "C" int gpp_stem_conv7x7_bn_relu(const float* in, const float* weight, co
         stem_kernel<__bf16, bf16x8><<<grid, 256, 0, st>>>(in, weight, bias, (__bf16*)out, H, W, Ho, Wo);
     else if (dtype == GPP_F16)
         stem_kernel<_Float16, f16x8><<<grid, 256, 0, st>>>(in, weight, bias, (_Float16*)out, H, W, Ho, Wo);
+    else
+        return GPP_ERR_UNSUPPORTED;
+    return result();
+}
+
+extern "C" int gpp_stem_pack_weights_f16(const float* host_weight_147x64, void* host_packed, size_t packed_bytes)
+{
+    // host-side helper: [147][64] float32 (HWIO flattened, BN scale folded) -> [64][232] f16, rows interleaved as for
+    // gpp_conv2d_igemm (row 16h + 4q + r of a 32-group = channel 8q + 4h + r), k = kh*32 + kw*3 + c, zero padded
+    if (!host_weight_147x64 || !host_packed || packed_bytes < (size_t)64 * MW_PITCH * 2) return GPP_ERR_BAD_ARG;
+    _Float16* dst = (_Float16*)host_packed;
+    for (int pos = 0; pos < 64; ++pos) {
+        const int g = pos / 32, within = pos % 32, h = within / 16, q = (within % 16) / 4, r = within % 4;
+        const int n = g * 32 + 8 * q + 4 * h + r;
+        for (int k = 0; k < MW_PITCH; ++k) {
+            const int kh = k / 32, kc = k % 32;
+            float v = 0.0f;
+            if (k < 224 && kc < 21) v = host_weight_147x64[(kh * 21 + kc) * 64 + n];
+            dst[pos * MW_PITCH + k] = (_Float16)v;
+        }
+    }
+    return GPP_OK;
+}
+
+extern "C" int gpp_stem_conv7x7_bn_relu_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
+                                             int dtype, int B, int H, int W, void* stream)
+{
+    if (!in || !packed_weight_f16 || !bias || !out || B <= 0 || H <= 0 || W <= 0) return GPP_ERR_BAD_ARG;
+    if (((uintptr_t)out | (uintptr_t)packed_weight_f16) & 15) return GPP_ERR_ALIGN;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const int tiles = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * B;
+    const unsigned grid = (unsigned)(tiles < 768 ? tiles : 768);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GPP_BF16)
+        stem_mfma_kernel<__bf16, bf16x8><<<grid, 256, 0, st>>>(in, (const _Float16*)packed_weight_f16, bias, (__bf16*)out, B, H, W, Ho, Wo);
+    else if (dtype == GPP_F16)
+        stem_mfma_kernel<_Float16, f16x8><<<grid, 256, 0, st>>>(in, (const _Float16*)packed_weight_f16, bias, (_Float16*)out, B, H, W, Ho, Wo);
     else
         return GPP_ERR_UNSUPPORTED;
     return result();

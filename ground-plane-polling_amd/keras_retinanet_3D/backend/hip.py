@@ -78,6 +78,10 @@ def _declare(lib):
     lib.gpp_conv2d_igemm.argtypes = [ctypes.POINTER(ConvDesc), c_void_p]
     lib.gpp_stem_conv7x7_bn_relu.restype = c_int
     lib.gpp_stem_conv7x7_bn_relu.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.gpp_stem_conv7x7_bn_relu_mfma.restype = c_int
+    lib.gpp_stem_conv7x7_bn_relu_mfma.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.gpp_stem_pack_weights_f16.restype = c_int
+    lib.gpp_stem_pack_weights_f16.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.gpp_maxpool3x3s2_same.restype = c_int
     lib.gpp_maxpool3x3s2_same.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.gpp_relu.restype = c_int
@@ -147,3 +151,13 @@ def ptr(t):
         return None
     assert t.is_contiguous(), 'gpp kernels need dense tensors'
     return ctypes.c_void_p(t.data_ptr())
+
+
+def pack_stem_weights(kernel_147x64, device):
+    """ [147][64] float32 folded stem kernel -> device tensor holding the [64][232] f16 image of the MFMA stem """
+    import numpy as np
+    import torch
+    src = np.ascontiguousarray(kernel_147x64, dtype=np.float32)
+    dst = np.zeros((64, 232), dtype=np.float16)
+    check(lib().gpp_stem_pack_weights_f16(src.ctypes.data_as(c_void_p), dst.ctypes.data_as(c_void_p), dst.nbytes), 'gpp_stem_pack_weights_f16')
+    return torch.as_tensor(dst).to(device).contiguous()

@@ -131,7 +131,7 @@ class RetinaNet3D(object):
             if k.shape != (kh, kw, cin, cout):
                 raise ValueError('weight {} has shape {}, expected {}'.format(conv, k.shape, (kh, kw, cin, cout)))
             if conv == 'conv1':
-                self.stem_w = torch.as_tensor(k.reshape(147, 64)).to(dev).contiguous()
+                self.stem_w = hip.pack_stem_weights(k.reshape(147, 64), dev)
                 self.stem_b = torch.as_tensor(b).to(dev).contiguous()
             else:
                 put(conv, k, b)

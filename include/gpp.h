@@ -158,6 +158,13 @@ int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
  * ---------------------------------------------------------------------------------------- */
 int gpp_stem_conv7x7_bn_relu(const float* in, const float* weight, const float* bias, void* out, int dtype,
                              int B, int H, int W, void* stream);
+/* MFMA form of the stem (the one the model uses): float32 input and the packed weights are rounded to f16
+ * (11-bit significand) on the fly, accumulated in float32 by v_mfma_f32_16x16x32_f16.  packed_weight_f16 is
+ * the [64][232] f16 image that the HOST-side helper gpp_stem_pack_weights_f16 produces from the [147][64]
+ * float32 folded kernel (14 848 elements = 29 696 bytes; both pointers of the helper are host pointers). */
+int gpp_stem_pack_weights_f16(const float* host_weight_147x64, void* host_packed, size_t packed_bytes);
+int gpp_stem_conv7x7_bn_relu_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
+                                  int dtype, int B, int H, int W, void* stream);
 int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B, int H, int W, int C, void* stream);
 int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream);
 /* batched form: image b reads `count` elements at in + b*in_bstride, writes out + b*out_bstride */
@@ -208,8 +215,8 @@ int gpp_detect_f32(const float* cls_logits, const float* regression, const float
 #define GPP_OP_DETECT 5
 #define GPP_OP_POLL 6
 
-typedef struct gpp_stem_desc { const float* in; const float* weight; const float* bias; void* out;
-                               int32_t dtype, B, H, W; } gpp_stem_desc;
+typedef struct gpp_stem_desc { const float* in; const void* weight; const float* bias; void* out;
+                               int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem) */
 typedef struct gpp_pool_desc { const void* in; void* out; int32_t dtype, B, H, W, C, reserved; } gpp_pool_desc;
 typedef struct gpp_relu_desc { const void* in; void* out; int64_t in_bstride, out_bstride, count;
                                int32_t dtype, B; } gpp_relu_desc;

@@ -15,8 +15,8 @@ freeze_bn => moving statistics), and TF semantics for 'same' padding and nearest
 Two modes
   * float32 throughout, BatchNormalization applied literally (the reference semantics);
   * `storage` = 'bf16' | 'f16': BN folded into the convolution, weights and every stored
-    activation rounded to the 16-bit storage type of the HIP path, float32 accumulation --
-    the arithmetic the GPU performs, up to summation order.
+    activation rounded to the 16-bit storage type of the HIP path (the stem rounds image and
+    weights to f16), float32 accumulation -- the arithmetic the GPU performs, up to summation order.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
@@ -73,7 +73,7 @@ class Net(object):
         self.q = _quantizer(storage)
 
     # conv + frozen BN (+ ReLU); literal BN in float32 mode, folded + rounded weights in storage mode
-    def conv_bn(self, x, conv, bn, stride=1, pad=None, relu=True, add=None, quant_weights=True):
+    def conv_bn(self, x, conv, bn, stride=1, pad=None, relu=True, add=None, quant_weights=True, f16_operands=False):
         w = self.w
         k = torch.as_tensor(w[conv + '/kernel'])
         gamma, beta = torch.as_tensor(w[bn + '/gamma']), torch.as_tensor(w[bn + '/beta'])
@@ -86,6 +86,8 @@ class Net(object):
             s = gamma.double() / torch.sqrt(var.double() + BN_EPS)
             kf = (k.double() * s[None, None, None, :]).float()
             bf = (beta.double() - mean.double() * s).float()
+            if f16_operands:      # the MFMA stem rounds image and weights to f16 (csrc/stem.hip), float32 accumulation
+                x, kf = x.half().float(), kf.half().float()
             y = _conv(x, self.q(kf) if quant_weights else kf, stride=stride, pad=pad) + bf[None, :, None, None]
         if add is not None:
             y = y + add
@@ -109,7 +111,7 @@ class Net(object):
         return '{}{}'.format(stage + 2, chr(ord('a') + block))
 
     def resnet(self, x):
-        x = self.conv_bn(x, 'conv1', 'bn_conv1', stride=2, pad=3, quant_weights=False)
+        x = self.conv_bn(x, 'conv1', 'bn_conv1', stride=2, pad=3, quant_weights=False, f16_operands=True)
         ph = _same_pad(x.shape[2], 3, 2)
         pw = _same_pad(x.shape[3], 3, 2)
         x = F.max_pool2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf')), 3, 2)

@@ -26,6 +26,18 @@ def test_stem_matches_torch(B, H, W, dtype, tdt, eps):
     err = (got - ref).abs()
     assert bool((err <= eps * ref.abs() + 2e-3).all()), err.max().item()
 
+    # MFMA stem (the one the model uses): input and weights rounded to f16, float32 accumulation.
+    # Rigorous bound: every product carries <= 2 * 2^-11 relative rounding -> 2^-10 * sum |x||w|.
+    bound = F.conv2d(F.pad(x.abs().permute(0, 3, 1, 2), (3, 3, 3, 3)), k.abs().permute(3, 2, 0, 1), None, stride=2).permute(0, 2, 3, 1)
+    out2 = torch.full((B, Ho, Wo, 64), float('nan'), dtype=tdt, device=dev)
+    packed = hip.pack_stem_weights(k.reshape(147, 64).numpy(), dev)
+    hip.check(hip.lib().gpp_stem_conv7x7_bn_relu_mfma(hip.ptr(xd), hip.ptr(packed), hip.ptr(bd), hip.ptr(out2), dtype, B, H, W, hip.stream_ptr()))
+    got2 = out2.float().cpu()
+    assert torch.isfinite(got2).all()
+    err2 = (got2 - ref).abs()
+    assert bool((err2 <= eps * ref.abs() + 2.0 ** -10 * bound + 2e-3).all()), err2.max().item()
+    assert err2.mean().item() < 0.1 * (2.0 ** -10 * bound).mean().item() + eps * ref.abs().mean().item()
+
 
 @pytest.mark.parametrize('B,H,W,C', [(2, 19, 27, 64), (1, 20, 28, 64), (1, 201, 667, 64)])
 def test_maxpool_matches_torch(B, H, W, C):
