@@ -106,8 +106,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
+    force_dist = os.environ.get('GPP_BENCH_FORCE_DIST') == '1'      # exercise the RCCL path on a single GPU
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
@@ -142,22 +144,22 @@ def main():
         ev = None if k is None else [e.value for e in events[2 * n_tagged * k: 2 * n_tagged * (k + 1)]]
         model.run_plan(plan, ev)
         packed = D.pack_outputs(model.outputs(plan))
-        return D.gather_detections(packed) if world > 1 else packed
+        return D.gather_detections(packed) if (world > 1 or force_dist) else packed
 
     for _ in range(args.warmup):
         out = step()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -191,7 +193,7 @@ def main():
                        'achieved_tflops_whole_path': round(plan.flops * args.steps / elapsed / 1e12, 1)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': None,
-                         'kernel': 'conv_igemm_kernel<{},256,256,2,4,2> on pyramid_regression_0..3 (3x3, 512->512, 5 levels, M={})'.format(
+                         'kernel': 'conv_igemm_kernel<{},256,256,2,4,2> on pyramid_regression_1..3 (3x3, 512->512, 5 levels, M={})'.format(
                              args.dtype, B * (plan.n_anchors // 12)),
                          'gflop_per_launch': round(flops_per_launch / 1e9, 1), 'mean_launch_ms': round(mean_ms, 4),
                          'launches_timed': len(durations)},
@@ -201,7 +203,7 @@ def main():
         print(json.dumps(rec))
     for e in events:
         lib.gpp_event_destroy(e)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

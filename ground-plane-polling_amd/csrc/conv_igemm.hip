@@ -546,8 +546,10 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
     // 256x256 tile (8 wavefronts, 1 workgroup / CU) halves the L2 -> LDS traffic per FLOP; it pays
     // when there are enough tiles for two rounds over the 256 CUs and enough K-steps to amortise
     // its longer prologue/epilogue.  (256x128 with a 3-deep ring is kept for experiments only.)
-    const int64_t big_blocks = ((rows + 255) / 256) * (d.C_out / 256);
-    if (d.tile_hint == 512 || (d.tile_hint == 0 && d.C_out % 256 == 0 && big_blocks >= 512 && nk >= 8))
+    const int n256 = (d.C_out + 255) / 256;
+    const int64_t big_blocks = ((rows + 255) / 256) * n256;
+    const bool n_fits = d.C_out >= 256 && n256 * 256 * 7 <= d.C_out * 8;      // at most 1/8 of the N tiles is padding
+    if (d.tile_hint == 512 || (d.tile_hint == 0 && n_fits && big_blocks >= 512 && nk >= 8))
         return (d.reserved & 8) ? launch<DT, 256, 256, 2, 4, 2, false>(d, st) : launch<DT, 256, 256, 2, 4, 2, true>(d, st);
     if (d.tile_hint == 256) return launch<DT, 256, 128, 4, 2, 3, false>(d, st);
     return (d.reserved & 4) ? launch<DT, 128, 128, 2, 2, 2, true>(d, st) : launch<DT, 128, 128, 2, 2, 2, false>(d, st);

@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* __restrict
     const float4* src = (const float4*)(cls + ((int64_t)b * n_anchors + a) * 8);
     const float4 v0 = src[0], v1 = src[1];
     const float l[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    // cheap exact reject: score = sigmoid(max logit) up to 1e-7; sigmoid(-3.5) = 0.029, and every
+    // caller-supplied threshold >= 0.03 is therefore decided without evaluating the 8 sigmoids
+    const float lmax = fmaxf(fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3])), fmaxf(fmaxf(l[4], l[5]), fmaxf(l[6], l[7])));
+    if (thr >= 0.03f && lmax < -3.5f) return;
     const Folded f = fold8(l);
     if (f.score > thr) {
         const int slot = atomicAdd(&counts[b], 1);

@@ -145,6 +145,8 @@ class RetinaNet3D(object):
             put(name, k, b)
         k, b = W.fused_regression_outputs(weights)
         put('pyramid_regression_ops', k, b)
+        k, b = W.fused_tower_inputs(weights)
+        put('pyramid_towers_0', k, b)
 
     # ------------------------------------------------------------------ plan
     def _anchor_table(self, hw):
@@ -246,21 +248,28 @@ class RetinaNet3D(object):
         plan.features.update({'P{}'.format(i + 3): P[i] for i in range(5)})
 
         # ---- heads: every layer is one grouped launch over the five levels
-        def tower(prefix, width, tag=0):
-            src = P
-            for i in range(4):
+        # layer 0 of the three towers shares its input: one fused launch (C_out = 896) into a wide
+        # tensor; layers 1..3 read their channel slice of it (in_pitch > C_in)
+        wide, wide_maps = pyramid(896)
+        self._conv(plan, 'pyramid_towers_0', P, wide_maps, 3, pad=(1, 1), relu=True)
+
+        def slice_of(maps, c0, c):
+            return [C.FMap(m.buf, B, m.H, m.W, c, off=m.off + c0, bstride=m.bstride, pitch=m.pitch) for m in maps]
+
+        def tower(prefix, width, src, tag=0):
+            for i in range(1, 4):
                 _, dst = pyramid(width)
                 self._conv(plan, '{}_{}'.format(prefix, i), src, dst, 3, pad=(1, 1), relu=True, tag=tag)
                 src = dst
             return src
 
-        reg_t = tower('pyramid_regression', 512, tag=1)
+        reg_t = tower('pyramid_regression', 512, slice_of(wide_maps, 0, 512), tag=1)
         plan.regression, reg_o = pyramid(144, torch.float32)
         self._conv(plan, 'pyramid_regression_ops', reg_t, reg_o, 3, pad=(1, 1), out_f32=True)
-        dim_t = tower('pyramid_regression_dim', 128)
+        dim_t = tower('pyramid_regression_dim', 128, slice_of(wide_maps, 768, 128))
         plan.regression_dim, dim_o = pyramid(36, torch.float32)
         self._conv(plan, 'pyramid_regression_dim', dim_t, dim_o, 3, pad=(1, 1), out_f32=True)
-        cls_t = tower('pyramid_classification', 256)
+        cls_t = tower('pyramid_classification', 256, slice_of(wide_maps, 512, 256))
         plan.cls_logits, cls_o = pyramid(96, torch.float32)
         self._conv(plan, 'pyramid_classification', cls_t, cls_o, 3, pad=(1, 1), out_f32=True)
 

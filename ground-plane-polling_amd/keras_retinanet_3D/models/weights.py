@@ -174,3 +174,13 @@ def fused_regression_outputs(weights):
     kernel = np.concatenate([weights[n + '/kernel'] for n in names], axis=3)
     bias = np.concatenate([weights[n + '/bias'] for n in names], axis=0)
     return kernel.astype(np.float32), bias.astype(np.float32)
+
+
+def fused_tower_inputs(weights):
+    """ The first layer of the three head towers (pyramid_regression_0, pyramid_classification_0,
+    pyramid_regression_dim_0; retinanet.py:100-107,52-60,151-158) read the same pyramid feature: one
+    C_out = 512 + 256 + 128 = 896 layer, channel order [regression | classification | dimension]. """
+    names = ['pyramid_regression_0', 'pyramid_classification_0', 'pyramid_regression_dim_0']
+    kernel = np.concatenate([weights[n + '/kernel'] for n in names], axis=3)
+    bias = np.concatenate([weights[n + '/bias'] for n in names], axis=0)
+    return kernel.astype(np.float32), bias.astype(np.float32)

@@ -47,7 +47,7 @@ def gather_detections(packed_local, shard_sizes=None, group=None):
     """ all-gather the packed detections of every rank -> (B_global, 100, 35) on every rank """
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return packed_local
     world = dist.get_world_size(group)
     if shard_sizes is None:

@@ -1,6 +1,7 @@
-""" Per-layer table from a rocprofv3 --kernel-trace CSV of bench.py (last complete step). """
+""" Per-launch table from a rocprofv3 --kernel-trace CSV of bench.py (last complete step). """
 import csv
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,38 +9,62 @@ sys.path.insert(0, os.path.join(ROOT, 'ground-plane-polling_amd'))
 from keras_retinanet_3D.models import weights as W  # noqa: E402
 
 
-def op_names(backbone):
-    names = ['conv1(stem)', 'pool1']
+def conv_names(backbone):
+    names = []
     for stage, n in enumerate(W.BLOCKS[backbone]):
         for b in range(n):
             nm = W.block_name(backbone, stage, b)
             names += ['res%s_2a' % nm, 'res%s_2b' % nm] + (['res%s_br1' % nm] if b == 0 else []) + ['res%s_2c' % nm]
-    names += ['C5_reduced', 'P5', 'C4_reduced', 'P4', 'C3_reduced', 'P3', 'P6', 'C6_relu', 'P7']
-    names += ['reg_%d' % i for i in range(4)] + ['reg_ops'] + ['dim_%d' % i for i in range(4)] + ['dim_out']
-    names += ['cls_%d' % i for i in range(4)] + ['cls_out', 'memset', 'candidates', 'nms', 'copy_counts', 'canon_planes', 'poll']
+    names += ['C5_reduced', 'P5', 'C4_reduced', 'P4', 'C3_reduced', 'P3', 'P6', 'P7']
+    names += ['heads_0(fused)'] + ['reg_%d' % i for i in range(1, 4)] + ['reg_ops'] + ['dim_%d' % i for i in range(1, 4)] + ['dim_out']
+    names += ['cls_%d' % i for i in range(1, 4)] + ['cls_out']
     return names
+
+
+def short(k):
+    m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>', k)
+    if m:
+        return 'igemm %sx%s w%sx%s s%s%s' % (m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), ' pipe' if m.group(7) in ('true', '1') else '')
+    for key in ('stem_mfma', 'stem_kernel', 'maxpool', 'relu', 'splitk_reduce', 'candidates', 'nms', 'canonical_planes', 'poll'):
+        if key in k:
+            return key
+    return k[:40]
 
 
 def main(path, backbone='resnet50'):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    ours = [r for r in rows if 'at::native' not in r['Kernel_Name']]
-    # steps start at every stem kernel
-    starts = [i for i, r in enumerate(ours) if 'stem_kernel' in r['Kernel_Name']]
-    i0 = starts[-1]
-    step = ours[i0:]
-    names = [n for n in op_names(backbone) if n not in ('memset', 'copy_counts')]
-    step = [r for r in step if 'rocclr' not in r['Kernel_Name']][:len(names)]
-    tot = 0.0
+    ours = [r for r in rows if 'at::native' not in r['Kernel_Name'] and 'rocclr' not in r['Kernel_Name']]
+    starts = [i for i, r in enumerate(ours) if 'stem' in r['Kernel_Name']]
+    step = ours[starts[-2]:starts[-1]] if len(starts) > 1 else ours[starts[-1]:]
+    names = conv_names(backbone)
+    ci = 0
     t0 = int(step[0]['Start_Timestamp'])
-    for n, r in zip(names, step):
-        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-        tot += d
+    total = 0.0
+    groups = {}
+    for r in step:
         k = r['Kernel_Name']
-        short = 'igemm128x128' if '128, 128' in k else 'igemm128x64' if '128, 64' in k else k.split('(')[0][-30:]
-        print('%-16s %-30s %9.1f us   grid %s  start +%.1f us' % (n, short, d, r.get('Grid_Size', ''), (int(r['Start_Timestamp']) - t0) / 1e3))
+        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        total += d
+        if 'conv_igemm' in k:
+            name = names[ci] if ci < len(names) else '?'
+            ci += 1
+        elif 'splitk_reduce' in k:
+            name = '  (split-K reduce)'
+        else:
+            name = short(k)
+        grp = 'stem+pool' if name in ('stem_mfma', 'stem_kernel', 'maxpool') else \
+              'backbone' if name.startswith('res') else 'heads' if name[:3] in ('reg', 'dim', 'cls', 'hea') else \
+              'decode+poll' if name in ('candidates', 'nms', 'canonical_planes', 'poll') else \
+              'fpn' if name[0] in 'CP' or name == 'relu' else 'other'
+        if name.startswith('  ('):
+            grp = last_grp
+        last_grp = grp
+        groups[grp] = groups.get(grp, 0.0) + d
+        print('%-20s %-28s %9.1f us   +%.1f us' % (name, short(k), d, (int(r['Start_Timestamp']) - t0) / 1e3))
     wall = (int(step[-1]['End_Timestamp']) - t0) / 1e3
-    print('sum of kernel durations %.1f us, wall of the step %.1f us' % (tot, wall))
+    print('sum of kernel durations %.1f us, wall of the step %.1f us' % (total, wall))
+    print('by group: ' + ', '.join('%s %.0f us' % kv for kv in groups.items()))
 
 
 if __name__ == '__main__':
