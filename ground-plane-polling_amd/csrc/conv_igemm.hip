@@ -7,7 +7,7 @@
 // for every layer with C_in % 64 == 0 (everything except the 3-channel stem, csrc/stem.hip).
 //
 // GEMM view (one launch = up to 5 feature maps sharing the weights):
-//   C[M = batch*Ho*Wo pixels][N = C_out] = A[M][K] * B[K][N],  K = (kh, kw, c_in)
+//   C[M = batch*Ho*Wo pixels][N = C_out] = A[M][K] * B[K][N],  K = (c_in chunk of 64, kh, kw, 64 channels)
 //   A is never materialised: for K-step (tap, 64-channel chunk) row m is the 128 contiguous
 //   bytes in[b, oy*s - pt + kh, ox*s - pl + kw, c0:c0+64]  (or the zero page outside the image).
 //
@@ -195,33 +195,37 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     const int gchunk = (lane & 7) ^ srow;
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, d.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.weight, 0, d.weight_bytes, 0x00020000);
-    int a_rowbase[A_IT], a_iy0[A_IT], a_ix0[A_IT], a_voff[A_IT];
+    // Per staged row: byte offset of its tap (0,0) source (may be negative at the border -- it is
+    // only used when the tap is valid) and a validity mask: bit kh = input row iy0+kh inside the
+    // image, bit 8+kw = input column ix0+kw inside.  Per K-step the source is base + (kh*W + kw)*pitch
+    // (a scalar) when both bits are set, else kOutOfRange: ~4 VALU per row and step.
+    int a_base[A_IT], a_mask[A_IT], a_voff[A_IT];
+    const int pitch2 = d.in_pitch * 2;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + (wave * A_IT + i) * 8 + srow;
+        a_mask[i] = 0;
+        a_base[i] = 0;
         if (m < Mg) {
             const int b = m / HoWo, p = m - b * HoWo;
             const int oy = p / W_out, ox = p - oy * W_out;
-            a_iy0[i] = oy * d.stride - d.pad_top;
-            a_ix0[i] = ox * d.stride - d.pad_left;
-            a_rowbase[i] = (int)((in_off + (int64_t)b * in_bs) * 2) + gchunk * 16;
-        } else {
-            a_iy0[i] = -(1 << 28); a_ix0[i] = 0; a_rowbase[i] = 0;
+            const int iy0 = oy * d.stride - d.pad_top, ix0 = ox * d.stride - d.pad_left;
+            int mask = 0;
+            for (int k = 0; k < d.KH; ++k) mask |= ((unsigned)(iy0 + k) < (unsigned)H_in) << k;
+            for (int k = 0; k < d.KW; ++k) mask |= ((unsigned)(ix0 + k) < (unsigned)W_in) << (8 + k);
+            a_mask[i] = mask;
+            a_base[i] = (int)((in_off + (int64_t)b * in_bs) * 2) + gchunk * 16 + (iy0 * W_in + ix0) * pitch2;
         }
     }
     int w_voff[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) w_voff[i] = (n0 + (wave * B_IT + i) * 8 + srow) * Ktot * 2 + gchunk * 16;
-    const int pitch2 = d.in_pitch * 2;
 
-    // per tap (every cpt K-steps): where this lane's rows read from, or kOutOfRange for padding
     auto set_tap = [&](int kh, int kw) {
+        const int delta = (kh * W_in + kw) * pitch2;
+        const int need = (1 << kh) | (1 << (8 + kw));
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-            const bool ok = (unsigned)iy < (unsigned)H_in && (unsigned)ix < (unsigned)W_in;
-            a_voff[i] = ok ? a_rowbase[i] + (iy * W_in + ix) * pitch2 : kOutOfRange;
-        }
+        for (int i = 0; i < A_IT; ++i) a_voff[i] = ((a_mask[i] & need) == need) ? a_base[i] + delta : kOutOfRange;
     };
     // per K-step: only scalar offsets change (cc*128 bytes into the pixel, ks*128 bytes into the weight row)
     auto stage = [&](int buf, int cc, int ks) {
@@ -254,15 +258,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     // stage ks only (later stages stay in flight across the barrier); after the barrier every
     // wave's loads of stage ks have landed and every wave has finished reading the buffer of step
     // ks-1, which is exactly the buffer the next prefetch (stage ks+PF) overwrites.
-    int cc = ks0 % cpt, kw = (ks0 / cpt) % d.KW, kh = (ks0 / cpt) / d.KW, issued = 0, ibuf = 0;
+    // K order: 64-channel chunk OUTER, tap INNER (weights are packed to match): the nine taps of one
+    // chunk re-read the same few input rows back to back, so they hit in the XCD's L2 instead of being
+    // re-fetched across the fabric once per tap
+    const int taps = d.KH * d.KW;
+    int cc = ks0 / taps, kw = (ks0 % taps) % d.KW, kh = (ks0 % taps) / d.KW, issued = 0, ibuf = 0;
     set_tap(kh, kw);
     auto issue_next = [&]() {
         stage(ibuf, cc, ks0 + issued);
-        if (++cc == cpt) {
-            cc = 0;
-            if (++kw == d.KW) { kw = 0; ++kh; }
-            set_tap(kh, kw);
+        if (++kw == d.KW) {
+            kw = 0;
+            if (++kh == d.KH) { kh = 0; ++cc; }
         }
+        set_tap(kh, kw);
         ++issued;
         if (++ibuf == STAGES) ibuf = 0;
     };
@@ -300,11 +308,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
             else glds16(rw, w_voff[idx >= A_IT ? idx - A_IT : 0], so_w, sb + (idx - A_IT) * 8 * kRowBytes);
         };
         auto advance_tap = [&]() {
-            if (++cc == cpt) {
-                cc = 0;
-                if (++kw == d.KW) { kw = 0; ++kh; }
-                set_tap(kh, kw);
+            if (++kw == d.KW) {
+                kw = 0;
+                if (++kh == d.KH) { kh = 0; ++cc; }
             }
+            set_tap(kh, kw);
             ++issued;
         };
         vec8 a0[MF], b0[NF], a1[MF], b1[NF];
@@ -560,6 +568,7 @@ int validate(const gpp_conv_desc& d)
     if (!d.in || !d.weight || !d.out) return GPP_ERR_BAD_ARG;
     if (d.dtype != GPP_BF16 && d.dtype != GPP_F16) return GPP_ERR_UNSUPPORTED;
     if (d.batch <= 0 || d.C_in <= 0 || d.C_out <= 0 || d.KH <= 0 || d.KW <= 0) return GPP_ERR_BAD_ARG;
+    if (d.KH > 8 || d.KW > 8) return GPP_ERR_UNSUPPORTED;           // tap validity masks are 8 + 8 bits
     if (d.C_in % 64 != 0 || d.C_out % 4 != 0) return GPP_ERR_UNSUPPORTED;
     if (d.stride != 1 && d.stride != 2) return GPP_ERR_UNSUPPORTED;
     if (d.n_groups < 1 || d.n_groups > GPP_MAX_GROUPS) return GPP_ERR_BAD_ARG;

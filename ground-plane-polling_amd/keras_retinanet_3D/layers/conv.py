@@ -48,13 +48,14 @@ class FMap(object):
 
 def pack_weight(kernel_hwio, dtype, device):
     """ Keras HWIO float32 kernel (KH, KW, C_in, C_out) -> device tensor
-    [C_out rounded up to 256][KH*KW*C_in] in the compute type, K ordered (kh, kw, c_in). """
+    [C_out rounded up to 256][KH*KW*C_in] in the compute type, K ordered (64-channel chunk, kh, kw, channel). """
     import torch
     k = torch.as_tensor(np.ascontiguousarray(kernel_hwio, dtype=np.float32))
     KH, KW, Cin, Cout = k.shape
     rows = ((Cout + 255) // 256) * 256
     w = torch.zeros((rows, KH * KW * Cin), dtype=torch.float32)
-    w[:Cout] = k.permute(3, 0, 1, 2).reshape(Cout, KH * KW * Cin)
+    # K order (chunk of 64 input channels, kh, kw, 64 channels): see include/gpp.h
+    w[:Cout] = k.permute(3, 0, 1, 2).reshape(Cout, KH * KW, Cin // 64, 64).permute(0, 2, 1, 3).reshape(Cout, KH * KW * Cin)
     w = w[weight_row_order(rows)]
     return w.to(torch_dtype(dtype)).to(device).contiguous()
 

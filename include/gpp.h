@@ -83,7 +83,8 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
  * One launch covers up to GPP_MAX_GROUPS independent feature maps that share the weights
  * (the five pyramid levels of a head layer, retinanet.py:257-281), each described by a
  * gpp_conv_group.  GEMM view per group: M = batch*H_out*W_out output pixels, N = C_out,
- * K = KH*KW*C_in, K ordered (kh, kw, c_in).
+ * K = KH*KW*C_in, K ordered (c_in / 64, kh, kw, c_in % 64): the taps of one 64-channel chunk are
+ * adjacent so that their overlapping input rows are re-read from the XCD-local L2.
  *
  * Layouts (element = 2 bytes, GPP_BF16 or GPP_F16)
  *   in        pixel (b, y, x) of a group at  in + in_off + b*in_bstride + (y*W_in + x)*in_pitch,
