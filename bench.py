@@ -174,6 +174,13 @@ def main():
     flops_per_launch = float(np.mean(tagged_flops)) if tagged_flops else 0.0
     mean_ms = float(np.mean(durations)) if durations else float('nan')
     achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12 if durations else float('nan')
+    # HBM/fabric traffic of that kernel cannot be read live (PMC needs rocprofv3): report the committed
+    # measurement of the same kernel on the same workload (profiles/r1/dominant_kernel_pmc.*, tools/pmc_bench.sh)
+    traffic = None
+    pmc_path = os.path.join(ROOT, 'profiles', 'r1', 'dominant_kernel_pmc.json')
+    if os.path.isfile(pmc_path) and args.backbone == 'resnet50' and B == 8 and args.dtype == 'bf16':
+        with open(pmc_path) as f:
+            traffic = round(json.load(f)['traffic_bytes_per_launch'] / 1e6, 1)
     counts = plan.counts.cpu().numpy()
     dets = int((out[:, :, 15] > 0.05).sum().item())
 
@@ -192,7 +199,9 @@ def main():
                        'algorithmic_gflop_per_image': round(plan.flops / B / 1e9, 1),
                        'achieved_tflops_whole_path': round(plan.flops * args.steps / elapsed / 1e12, 1)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': traffic,
+                         'traffic_unit': 'MB per launch at the L2<->fabric interface (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
+                                         'algorithmic 192.1 MB)',
                          'kernel': 'conv_igemm_kernel<{},256,256,2,4,2> on pyramid_regression_1..3 (3x3, 512->512, 5 levels, M={})'.format(
                              args.dtype, B * (plan.n_anchors // 12)),
                          'gflop_per_launch': round(flops_per_launch / 1e9, 1), 'mean_launch_ms': round(mean_ms, 4),

@@ -1,0 +1,40 @@
+""" Aggregate tools/pmc_bench.sh output for the dominant kernel -> profiles/<round>/dominant_kernel_pmc.{txt,json} """
+import collections
+import csv
+import glob
+import json
+import sys
+
+src, out_prefix = sys.argv[1], sys.argv[2]
+GRID = 722 * 512
+agg = collections.defaultdict(list)
+for f in glob.glob(src + '/*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'conv_igemm_kernel<1, 256, 256' in r['Kernel_Name'] and int(r['Grid_Size']) == GRID:
+            agg[r['Counter_Name']].append(float(r['Counter_Value']))
+mean = {k: sum(v) / len(v) for k, v in agg.items()}
+read_b = 2.0 * mean['FETCH_SIZE'] * 1024
+write_b = mean['WRITE_SIZE'] * 1024
+alg_read, alg_write = 91504 * 512 * 2 + 512 * 4608 * 2, 91504 * 512 * 2
+lines = ['dominant kernel = conv_igemm_kernel<bf16,256,256,2,4,2,pipe>, grid 722 x 512 threads',
+         '(regression tower 3x3 512->512 over the 5 pyramid levels, M = 91504 rows, B = 8)',
+         'collected with tools/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline', '']
+for k in sorted(mean):
+    lines.append('%-28s launches=%3d  mean per launch %.6g' % (k, len(agg[k]), mean[k]))
+lines += ['', 'Fabric-side traffic per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE count KiB at the L2 <-> fabric',
+          'interface, Infinity-Cache hits included; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide 16 B/lane streams -> doubled;',
+          'WRITE_SIZE is exact for 16 B/lane stores):',
+          '  read  = 2 * FETCH_SIZE * 1024 = %.1f MB   (algorithmic %.1f MB = activations once + weights once)' % (read_b / 1e6, alg_read / 1e6),
+          '  write = WRITE_SIZE * 1024     = %.1f MB   (algorithmic %.1f MB)' % (write_b / 1e6, alg_write / 1e6),
+          '  total = %.1f MB' % ((read_b + write_b) / 1e6)]
+if 'TCC_HIT_sum' in mean:
+    lines.append('L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS) = %.3f' % (mean['TCC_HIT_sum'] / (mean['TCC_HIT_sum'] + mean['TCC_MISS_sum'])))
+if 'SQ_VALU_MFMA_BUSY_CYCLES' in mean and 'GRBM_GUI_ACTIVE' in mean:
+    lines.append('MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) = %.3f' % (mean['SQ_VALU_MFMA_BUSY_CYCLES'] / (mean['GRBM_GUI_ACTIVE'] / 8 * 1024)))
+if 'SQ_INSTS_VALU' in mean:
+    lines.append('VALU instructions per MFMA = %.2f' % (mean['SQ_INSTS_VALU'] / mean['SQ_INSTS_MFMA']))
+open(out_prefix + '.txt', 'w').write('\n'.join(lines) + '\n')
+json.dump({'kernel': 'conv_igemm_kernel<bf16,256,256,2,4,2,pipe>', 'grid': GRID, 'traffic_bytes_per_launch': read_b + write_b,
+           'read_bytes': read_b, 'write_bytes': write_b, 'algorithmic_bytes': alg_read + alg_write,
+           'counters': mean}, open(out_prefix + '.json', 'w'), indent=1)
+print('\n'.join(lines))
