@@ -86,6 +86,8 @@ def _declare(lib):
     lib.gpp_maxpool3x3s2_same.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.gpp_relu.restype = c_int
     lib.gpp_relu.argtypes = [c_void_p, c_void_p, c_int, c_int64, c_void_p]
+    lib.gpp_preprocess_u8_bgr.restype = c_int
+    lib.gpp_preprocess_u8_bgr.argtypes = [c_void_p] * 8 + [c_int] * 5 + [c_float] * 3 + [c_void_p]
     lib.gpp_detect_workspace_bytes.restype = c_int
     lib.gpp_detect_workspace_bytes.argtypes = [c_int, c_int64, ctypes.POINTER(c_size_t)]
     lib.gpp_detect_f32.restype = c_int

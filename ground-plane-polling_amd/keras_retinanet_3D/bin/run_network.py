@@ -35,7 +35,7 @@ import scipy.io
 
 from .. import models
 from ..utils import gpp_utils
-from ..utils.image import preprocess_image, read_image_bgr, resize_image
+from ..utils.image import compute_resize_scale, preprocess_image, read_image_bgr, resize_image
 
 
 def parse_args(args):
@@ -65,11 +65,15 @@ def make_output_tree(args):
     return output_dir
 
 
-def load_item(args, fn):
-    """ everything the reference does per image before the timer starts (:91-105) """
+def load_item(args, fn, on_device):
+    """ everything the reference does per image before the timer starts (:91-105); with a model that
+    preprocesses on the GPU (predict_on_frames) only the raw frame and the scale are prepared here """
     image_fp = os.path.join(args.image_dir, fn.replace('.txt', '.png'))
     raw_image = read_image_bgr(image_fp)
-    image, scale = resize_image(preprocess_image(raw_image))
+    if on_device:
+        image, scale = None, compute_resize_scale(raw_image.shape)
+    else:
+        image, scale = resize_image(preprocess_image(raw_image))
     P, P_inv = gpp_utils.load_calibration(os.path.join(args.calib_dir, fn), scale)
     return {'image_fp': image_fp, 'raw_image': raw_image, 'image': image, 'scale': scale, 'P': P, 'P_inv': P_inv}
 
@@ -101,16 +105,20 @@ def main(args=None):
     files = os.listdir(args.calib_dir)
     j = 0
     for start in range(0, len(files), max(args.batch_size, 1)):
-        items = [load_item(args, fn) for fn in files[start:start + max(args.batch_size, 1)]]
+        on_device = hasattr(model, 'predict_on_frames')
+        items = [load_item(args, fn, on_device) for fn in files[start:start + max(args.batch_size, 1)]]
         # images of one batch must share a shape (KITTI frames of one drive do); split otherwise
         groups = {}
         for it in items:
-            groups.setdefault(it['image'].shape, []).append(it)
+            groups.setdefault(it['raw_image'].shape, []).append(it)
         for group in groups.values():
-            inputs = [np.stack([it['image'] for it in group]), np.stack([it['P_inv'] for it in group]),
-                      np.tile(plane_params[None], (len(group), 1, 1))]
+            P_inv = np.stack([it['P_inv'] for it in group])
+            planes = np.tile(plane_params[None], (len(group), 1, 1))
             t0 = time.time()
-            outputs = model.predict_on_batch(inputs)[:8]
+            if on_device:
+                outputs = model.predict_on_frames(np.stack([it['raw_image'] for it in group]), P_inv, planes)[0][:8]
+            else:
+                outputs = model.predict_on_batch([np.stack([it['image'] for it in group]), P_inv, planes])[:8]
             dt = time.time() - t0
             for k, it in enumerate(group):
                 print("Image {}: frame rate: {:.2f}".format(j, len(group) / dt))

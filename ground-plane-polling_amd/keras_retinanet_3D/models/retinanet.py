@@ -369,6 +369,53 @@ class RetinaNet3D(object):
         put(plan.planes, planes)
         return plan
 
+    # ------------------------------------------------------------------ raw frames (GPU preprocessing)
+    def stage_frames(self, frames_u8, P_inv, planes, min_side=800, max_side=1333):
+        """ frames_u8 (B, H, W, 3) uint8 BGR as utils.image.read_image_bgr returns them.  Uploads the raw
+        bytes and runs mean subtraction + bilinear resize on the device (csrc/preprocess.hip), i.e. what
+        bin/run_network.py:95-99 does on the host.  Returns (plan, scale). """
+        from ..utils import image as image_utils
+        torch = self.torch
+        frames = frames_u8 if isinstance(frames_u8, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(frames_u8))
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+            raise ValueError('frames must be (B, H, W, 3) uint8, got {} {}'.format(tuple(frames.shape), frames.dtype))
+        B, H, Wd = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        scale = image_utils.compute_resize_scale((H, Wd, 3), min_side, max_side)
+        Ho, Wo = int(np.rint(H * scale)), int(np.rint(Wd * scale))
+        key = (H, Wd, Ho, Wo)
+        if not hasattr(self, '_taps'):
+            self._taps = {}
+        if key not in self._taps:
+            y0, y1, wy = image_utils._axis_taps(Ho, H, scale)
+            x0, x1, wx = image_utils._axis_taps(Wo, Wd, scale)
+            dev = self.device
+            self._taps[key] = [torch.as_tensor(a.astype(np.int32)).to(dev) for a in (y0, y1)] + [torch.as_tensor(wy).to(dev)] + \
+                              [torch.as_tensor(a.astype(np.int32)).to(dev) for a in (x0, x1)] + [torch.as_tensor(wx).to(dev)]
+        y0, y1, wy, x0, x1, wx = self._taps[key]
+        pshape = tuple(planes.shape)
+        plan = self.plan_for(B, Ho, Wo, pshape[-2], len(pshape) == 3)
+        frames_d = frames.to(self.device, non_blocking=True).contiguous()
+        m = image_utils.IMAGENET_MEAN_BGR
+        hip.check(hip.lib().gpp_preprocess_u8_bgr(hip.ptr(frames_d), hip.ptr(plan.images), hip.ptr(y0), hip.ptr(y1), hip.ptr(wy),
+                                                  hip.ptr(x0), hip.ptr(x1), hip.ptr(wx), B, H, Wd, Ho, Wo,
+                                                  float(m[0]), float(m[1]), float(m[2]), hip.stream_ptr()), 'gpp_preprocess_u8_bgr')
+
+        def put(dst, src):
+            src_t = src if isinstance(src, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(src, dtype=np.float32))
+            dst.copy_(src_t.to(dtype=dst.dtype), non_blocking=True)
+
+        put(plan.P_inv, P_inv)
+        put(plan.planes, planes)
+        plan.keep_frames = frames_d
+        return plan, scale
+
+    def predict_on_frames(self, frames_u8, P_inv, planes):
+        """ predict_on_batch for raw uint8 BGR frames; returns (the 8 output arrays, scale).  P_inv must
+        have been computed for that scale (utils.image.compute_resize_scale). """
+        plan, scale = self.stage_frames(frames_u8, P_inv, planes)
+        self.run_plan(plan)
+        return [t.cpu().numpy() for t in self.outputs(plan)], scale
+
     # Keras-style conveniences used by the reference's scripts
     def predict(self, inputs, batch_size=None, verbose=0):
         return self.predict_on_batch(inputs)

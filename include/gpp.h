@@ -173,6 +173,18 @@ int gpp_relu_strided(const void* in, int64_t in_bstride, void* out, int64_t out_
                      int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Image preprocessing: uint8 BGR frames (B, H, W, 3) -> float32 (B, Ho, Wo, 3),
+ * ImageNet mean subtracted per channel, then bilinear resize.  Replaces the host-side
+ * utils/image.py:36-62 (preprocess_image) + :174-200 (resize_image -> cv2.resize INTER_LINEAR).
+ * y0/y1/wy (Ho entries) and x0/x1/wx (Wo entries) are the interpolation taps: source indices and the
+ * float32 weight of the second one, as cv2 derives them from the scale (half-pixel centres, border
+ * replicated); device arrays, computed once per input shape by the host.
+ * ---------------------------------------------------------------------------------------- */
+int gpp_preprocess_u8_bgr(const uint8_t* frames, float* out, const int32_t* y0, const int32_t* y1, const float* wy,
+                          const int32_t* x0, const int32_t* x1, const float* wx, int B, int H, int W, int Ho, int Wo,
+                          float mean_b, float mean_g, float mean_r, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Detection decode: sigmoid, orientation fold, score threshold, NMS, top-k, box / dimension
  * decode, -1 padding.  Replaces models/retinanet.py:72-73 (sigmoid), layers/_misc.py:133-141
  * + backend/common.py:43-81 (RegressBoxes), layers/_misc.py:186-187 + backend/common.py:23-40

@@ -141,3 +141,25 @@ def test_bad_inputs_raise(model50):
         models.load_model('synthetic:1', backbone_name='resnet34')        # models/resnet.py:61-68
     with pytest.raises(NotImplementedError):
         models.load_model('synthetic:1', backbone_name='vgg16')           # out of scope
+
+
+def test_run_network_cli_on_the_gpu(tmp_path):
+    """ the real CLI end to end: PNG + calibration files in, .mat + KITTI files out (synthetic weights) """
+    import scipy.io
+    from PIL import Image
+    from keras_retinanet_3D.bin import run_network
+    (tmp_path / 'img').mkdir(); (tmp_path / 'calib').mkdir(); (tmp_path / 'out').mkdir()
+    P2 = synthetic.KITTI_LIKE_P2
+    calib = 'P0: ' + ' '.join(['0'] * 12) + '\nP1: ' + ' '.join(['0'] * 12) + '\nP2: ' + ' '.join('%.12e' % v for v in P2.reshape(-1)) + '\n'
+    for k in range(3):
+        Image.fromarray(synthetic.synthetic_image(seed=k)[:, :, ::-1]).save(str(tmp_path / 'img' / ('%06d.png' % k)))
+        (tmp_path / 'calib' / ('%06d.txt' % k)).write_text(calib)
+    run_network.main(['synthetic:1234.h5', str(tmp_path / 'img'), str(tmp_path / 'calib'), synthetic.plane_database_path('1k'),
+                      str(tmp_path / 'out'), '--kitti', '--batch-size', '2'])
+    for k in range(3):
+        mat = scipy.io.loadmat(str(tmp_path / 'out' / 'synthetic:1234' / 'outputs' / 'full' / ('%06d.mat' % k)))
+        n = mat['scores'].shape[1]
+        assert n > 0 and mat['boxes'].shape == (n, 4) and mat['keypoints'].shape == (n, 8) and mat['locations'].shape == (n, 3)
+        assert np.all(np.diff(mat['scores'][0]) <= 0) and np.isfinite(mat['angles']).all()
+        txt = (tmp_path / 'out' / 'synthetic:1234' / 'outputs' / 'kitti' / ('%06d.txt' % k)).read_text()
+        assert txt.count('\n') == n and txt.startswith('Car -1 -1 ')

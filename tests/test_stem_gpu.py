@@ -61,3 +61,24 @@ def test_relu():
     out = torch.empty_like(x)
     hip.check(hip.lib().gpp_relu(hip.ptr(x), hip.ptr(out), hip.GPP_BF16, x.numel(), hip.stream_ptr()))
     assert torch.equal(out, torch.relu(x))
+
+
+def test_gpu_preprocessing_is_bit_identical_to_the_host_path():
+    """ uint8 frames -> (mean subtraction, bilinear resize) on the device == utils.image on the host """
+    import numpy as np
+    from keras_retinanet_3D import models
+    from keras_retinanet_3D.utils import image, synthetic
+    model = models.load_model('synthetic:3', backbone_name='resnet50')
+    frames = np.stack([synthetic.synthetic_image(seed=s) for s in (1, 2)])
+    planes = synthetic.load_plane_database('10').astype(np.float32)
+    scale = image.compute_resize_scale(frames.shape[1:])
+    _, P_inv = synthetic.synthetic_calibration(scale)
+    P_inv = np.tile(P_inv[None].astype(np.float32), (2, 1, 1))
+    plan, got_scale = model.stage_frames(frames, P_inv, planes)
+    want = np.stack([image.resize_image(image.preprocess_image(f))[0] for f in frames])
+    assert got_scale == scale and tuple(plan.images.shape) == want.shape == (2, 402, 1333, 3)
+    assert np.array_equal(plan.images.cpu().numpy(), want)
+    a, _ = model.predict_on_frames(frames, P_inv, planes)
+    b = model.predict_on_batch([want, P_inv, planes])
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y) or np.allclose(x, y, equal_nan=True)
