@@ -55,7 +55,9 @@ def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, clas
     if isinstance(filepath, dict):
         w = filepath
     elif isinstance(filepath, str) and filepath.startswith('synthetic'):
-        seed = int(filepath.split(':', 1)[1]) if ':' in filepath else 1234
+        import re
+        m = re.match(r'synthetic:(\d+)', filepath)          # 'synthetic:7', also 'synthetic:7.h5' (run_network strips 3 chars)
+        seed = int(m.group(1)) if m else 1234
         w = W.synthetic_weights(name, seed)
     else:
         w = W.load_weights(filepath)
