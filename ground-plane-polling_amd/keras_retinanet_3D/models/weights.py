@@ -92,17 +92,22 @@ def _normal(seed, name, shape, std):
 SYN_CLS_OUT_GAIN = 0.182      # classification logits ~ N(-4.6, 0.52): about 1e3 anchors of 137256 above 0.05
 SYN_REG_OUT_GAIN = 0.31       # regression deltas ~ N(0, 1)
 SYN_DIM_OUT_GAIN = 0.18       # dimension deltas ~ N(0, 1)
+# the deeper backbones end with somewhat larger pyramid features: same calibration target, measured the same way
+SYN_BACKBONE_OUT_SCALE = {'resnet50': 1.0, 'resnet101': 0.676, 'resnet152': 0.52}
 
 
 def synthetic_weights(backbone='resnet50', seed=1234):
     """ Seeded random weights with the exact architecture of `backbone` + FPN + heads. """
     w = {}
+    stage_blocks = {str(stage + 2): n for stage, n in enumerate(BLOCKS[backbone])}
     for conv, bn, kh, kw, cin, cout, _ in backbone_layers(backbone):
         w[conv + '/kernel'] = _normal(seed, conv, (kh, kw, cin, cout), np.sqrt(2.0 / (kh * kw * cin)))
         r = _rng(seed, bn)
         gamma = (1.0 + 0.1 * r.standard_normal(cout)).astype(np.float32)
         if bn.endswith('branch2c'):
-            gamma *= np.float32(0.3)          # keeps the residual stream from doubling per block
+            # keeps the residual stream O(1): 0.3 per block, less in the 23- / 36-block stages of ResNet-101 / -152
+            n_blocks = stage_blocks[bn[2]]
+            gamma *= np.float32(0.3 * min(1.0, np.sqrt(6.0 / n_blocks)))
         if bn.endswith('branch1'):
             gamma *= np.float32(0.7)
         w[bn + '/gamma'] = np.abs(gamma) + np.float32(0.05)
@@ -120,6 +125,7 @@ def synthetic_weights(backbone='resnet50', seed=1234):
             w[name + '/bias'] = np.zeros((cout,), np.float32)
         else:
             gain = SYN_CLS_OUT_GAIN if 'classification' in name else (SYN_DIM_OUT_GAIN if 'dim' in name else SYN_REG_OUT_GAIN)
+            gain *= SYN_BACKBONE_OUT_SCALE[backbone]
             w[name + '/kernel'] = _normal(seed, name, (3, 3, cin, cout), gain * np.sqrt(1.0 / (9 * cin)))
             w[name + '/bias'] = np.zeros((cout,), np.float32)
     # initializers.PriorProbability(0.01): bias = -log((1 - p) / p)   (initializers.py:23-39)
