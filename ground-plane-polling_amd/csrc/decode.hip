@@ -77,10 +77,13 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* __restrict
     const float4* src = (const float4*)(cls + ((int64_t)b * n_anchors + a) * 8);
     const float4 v0 = src[0], v1 = src[1];
     const float l[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    // cheap exact reject: score = sigmoid(max logit) up to 1e-7; sigmoid(-3.5) = 0.029, and every
-    // caller-supplied threshold >= 0.03 is therefore decided without evaluating the 8 sigmoids
+    // cheap exact rejects (the folded score is the largest of the 8 sigmoids, and the sigmoid used here is
+    // accurate to ~1e-7 and monotone to within that): (1) sigmoid(-3.0) = 0.0474 decides every threshold
+    // >= 0.048 without any exp; (2) one sigmoid of the largest logit with a 1e-5 guard band decides the rest.
+    // Only anchors inside the guard band or above the threshold pay for the exact 8-sigmoid fold.
     const float lmax = fmaxf(fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3])), fmaxf(fmaxf(l[4], l[5]), fmaxf(l[6], l[7])));
-    if (thr >= 0.03f && lmax < -3.5f) return;
+    if (thr >= 0.048f && lmax < -3.0f) return;
+    if (sigmoidf(lmax) < thr - 1e-5f) return;
     const Folded f = fold8(l);
     if (f.score > thr) {
         const int slot = atomicAdd(&counts[b], 1);
