@@ -534,7 +534,11 @@ int launch(gpp_conv_desc& d, hipStream_t st)
         nsplit = want < 1 ? 1 : want;
     }
     d.partial_rows = tiles * BM;
-    kernel<<<dim3((unsigned)(tiles * n_tiles), (unsigned)nsplit), dim3(64 * WM * WN), lds, st>>>(d);
+    // a layer with fewer K-steps than ring slots (1x1 convs with C_in = 64) only touches the first slots:
+    // declaring just those lets more workgroups share a CU, which is what the HBM-bound layers need
+    const int steps = (nk + nsplit - 1) / nsplit;
+    const int lds_used = (steps < STAGES ? steps : STAGES) * (BM + BN) * kRowBytes;
+    kernel<<<dim3((unsigned)(tiles * n_tiles), (unsigned)nsplit), dim3(64 * WM * WN), lds_used, st>>>(d);
     if (nsplit > 1) {
         const int64_t total = (int64_t)d.partial_rows * ((d.C_out + 7) / 8);
         splitk_reduce_kernel<DT><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(d, BM, n_tiles * BN, nsplit);
