@@ -81,3 +81,26 @@ def test_hip_decode_score_ties_break_by_anchor_index():
     assert np.array_equal(out[5].astype(np.int64), ref_idx)
     for got, want in zip(out[:5], ref):
         assert helpers.bits_equal(got, want)
+
+
+def test_hip_decode_large_k_prefix_and_fallback_paths():
+    """ > 8192 candidates: (a) the best-scoring prefix already yields 100 boxes; (b) with a tiny IoU threshold
+    nearly everything is suppressed, the prefix yields < 100 boxes and the full global sort takes over """
+    rng = np.random.default_rng(21)
+    anchors = A.anchors_for_image((160, 256))
+    n = anchors.shape[0]
+    logits = rng.normal(-1.0, 1.0, size=(1, n, 8)).astype(np.float32)
+    reg = rng.normal(0, 1, size=(1, n, 12)).astype(np.float32)
+    dim = rng.normal(0, 1, size=(1, n, 3)).astype(np.float32)
+    cls = decode_np.sigmoid(logits)
+    boxes = decode_np.regress_boxes(anchors[None], reg, cls)
+    dims = decode_np.regress_dims(dim)
+    for iou in (0.5, 1e-6):
+        ref, ref_idx = decode_np.filter_detections(boxes[0], dims[0], cls[0], nms_threshold=iou)
+        out = filter_detections(logits, reg, dim, anchors, nms_threshold=iou)
+        assert out[6][0] > 8192
+        kept = int((ref[2] > 0).sum())
+        assert kept == 100 if iou == 0.5 else kept < 100
+        for got, want in zip(out[:5], ref):
+            assert helpers.bits_equal(got[0], want)
+        assert np.array_equal(out[5][0].astype(np.int64), ref_idx)
