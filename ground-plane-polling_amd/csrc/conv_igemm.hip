@@ -8,21 +8,25 @@
 //
 // GEMM view (one launch = up to 5 feature maps sharing the weights):
 //   C[M = batch*Ho*Wo pixels][N = C_out] = A[M][K] * B[K][N],  K = (c_in chunk of 64, kh, kw, 64 channels)
-//   A is never materialised: for K-step (tap, 64-channel chunk) row m is the 128 contiguous
-//   bytes in[b, oy*s - pt + kh, ox*s - pl + kw, c0:c0+64]  (or the zero page outside the image).
+//   A is never materialised: for K-step (64-channel chunk, tap) row m is the 128 contiguous bytes
+//   in[b, oy*s - pt + kh, ox*s - pl + kw, c0:c0+64]; outside the image the buffer descriptor's range check
+//   makes the LDS-DMA deliver zeros.
 //
 // Work decomposition
-//   workgroup = 256 threads = 4 wavefronts (2 x 2), block tile BM x BN (128 x 128 or 128 x 64),
-//   wavefront tile (BM/2) x (BN/2) as (BM/32) x (BN/32) MFMA 16x16 accumulators.
-//   K-step = 64 channels of one tap; A and B tiles (128-byte rows) go HBM/L2 -> LDS with
-//   global_load_lds_dwordx4 (LDS-DMA, no VGPR staging), double buffered, one barrier per K-step.
-//   LDS rows are XOR-swizzled in 16-byte chunks (chunk ^= row & 7) by permuting the *source*
-//   chunk each lane fetches (the LDS-DMA destination is lane-linear), which makes the
-//   ds_read_b128 fragment reads conflict-free (bank = (addr/4) % 64, 16-lane groups).
-//   Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous range of
-//   tiles; the N-tiles of one M-tile are adjacent, so the activation rows are shared in L2.
+//   block tile BM x BN with WM x WN wavefronts and a STAGES-deep LDS ring, three configurations:
+//     256 x 256, 2 x 4 wavefronts (wave tile 128 x 64 = 8 x 4 MFMA 16x16 accumulators), 2 buffers, software-
+//               pipelined + explicitly interleaved main loop (PIPE): the big 3x3 layers, 1 workgroup / CU
+//     128 x 128 and 128 x 64, 2 x 2 wavefronts, 2 buffers: everything else, 2+ workgroups / CU, optional split-K
+//   K-step = 64 channels of one tap; A and B tiles (128-byte rows) go L2 -> LDS with buffer_load ... lds
+//   (LDS-DMA, no VGPR staging): per-lane offset fixed per tap, per-step offset scalar.
+//   LDS rows are XOR-swizzled in 16-byte chunks (chunk ^= row & 7) by permuting the *source* chunk each
+//   lane fetches (the LDS-DMA destination is lane-linear): conflict-free ds_read_b128 fragment reads.
+//   Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous range of tiles;
+//   the N-tiles of one M-tile are adjacent, so the activation rows are shared in that L2.
 //   Epilogue: straight from the accumulators (operands swapped + host-interleaved weight rows give
 //   every lane 8 consecutive output channels): bias, residual (+ nearest resize), ReLU, 16-byte stores.
+//   Split-K (gridDim.y) writes float32 partial tiles; splitk_reduce_kernel sums them in split order and
+//   runs the same epilogue.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
