@@ -6,9 +6,8 @@ read exactly once and only the 100 padded detections per image are written:
     RegressBoxes       /root/reference/keras_retinanet_3D/layers/_misc.py:103-153
     RegressDims        /root/reference/keras_retinanet_3D/layers/_misc.py:156-199
     FilterDetections   /root/reference/keras_retinanet_3D/layers/filter_detections.py:192-304
-(plus the sigmoid of models/retinanet.py:72-73).  Only the configuration that `load_model`
-produces is implemented: nms=True, class_specific_filter=True, orientation_specific_filter=False,
-one object class (the reference's only trained case, preprocessing/kitti.py:28-35).
+(plus the sigmoid of models/retinanet.py:72-73).  Implemented: nms=True|False, class_specific_filter=True|False (identical for one class),
+orientation_specific_filter=False, one object class (the reference's only trained case, preprocessing/kitti.py:28-35).
 """
 
 import numpy as np
@@ -28,9 +27,11 @@ class FilterDetections(object):
                  nms_threshold=NMS_THRESHOLD, score_threshold=SCORE_THRESHOLD, max_detections=MAX_DETECTIONS,
                  fused_regression=False):
         import torch
-        if not nms or orientation_specific_filter:
-            raise NotImplementedError('only nms=True, orientation_specific_filter=False is implemented on the device '
-                                      '(the configuration models.load_model produces)')
+        if orientation_specific_filter:
+            raise NotImplementedError('orientation_specific_filter=True is not implemented on the device '
+                                      '(models.load_model / convert_model.py default to False)')
+        if not nms:
+            nms_threshold = 2.0      # IoU never exceeds 1: nothing is suppressed, the kernel reduces to threshold + top-k
         self.batch, self.n_anchors, self.device = int(batch), int(n_anchors), device
         self.nms_threshold, self.score_threshold, self.max_detections = nms_threshold, score_threshold, max_detections
         self.fused = int(bool(fused_regression))

@@ -100,9 +100,10 @@ class RetinaNet3D(object):
     def __init__(self, weights, backbone_name='resnet50', dtype='bf16', nms=True, class_specific_filter=True,
                  orientation_specific_filter=False, name='retinanet-bbox'):
         import torch
-        if not nms or orientation_specific_filter:
-            raise NotImplementedError('the device decode implements nms=True, orientation_specific_filter=False '
+        if orientation_specific_filter:
+            raise NotImplementedError('the device decode implements orientation_specific_filter=False '
                                       '(what models.load_model produces by default)')
+        self.nms = bool(nms)
         self.name = name
         self.backbone_name = backbone_name.split('_')[0]
         if self.backbone_name not in W.BLOCKS:
@@ -310,7 +311,7 @@ class RetinaNet3D(object):
                         anchors.data_ptr(), plan.boxes.data_ptr(), plan.dimensions.data_ptr(), plan.scores.data_ptr(),
                         plan.labels.data_ptr(), plan.orientations.data_ptr(), plan.anchor_index.data_ptr(),
                         plan.counts.data_ptr(), plan.detect_ws.data_ptr(), plan.detect_ws.numel(), plan.n_anchors,
-                        B, anchor_utils.NUM_BASE_ANCHORS, 1, D, SCORE_THRESHOLD, NMS_THRESHOLD)
+                        B, anchor_utils.NUM_BASE_ANCHORS, 1, D, SCORE_THRESHOLD, NMS_THRESHOLD if self.nms else 2.0)
         plan.add(OP_DETECT, dd, 'filtered_detections')
 
         # ---- ground-plane polling (FitRoadPlanes)

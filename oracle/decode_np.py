@@ -169,7 +169,7 @@ def fold_classification(classification):
     return folded.max(axis=1), np.argmax(folded, axis=1)
 
 
-def filter_detections(boxes, dimensions, classification, score_threshold=0.05, max_detections=100, nms_threshold=0.5):
+def filter_detections(boxes, dimensions, classification, score_threshold=0.05, max_detections=100, nms_threshold=0.5, nms=True):
     """ One image.  boxes (A, 12), dimensions (A, 3), classification (A, 8) sigmoid scores ->
     [boxes (100, 12), dimensions (100, 3), scores (100,), labels (100,) i32, orientations (100,) i32],
     padded with -1, plus the selected anchor indices (for tests). """
@@ -177,8 +177,9 @@ def filter_detections(boxes, dimensions, classification, score_threshold=0.05, m
     dimensions = np.asarray(dimensions, dtype=F)
     scores_all, orient_all = fold_classification(classification)
     idx = np.nonzero(scores_all > F(score_threshold))[0]
-    keep = non_max_suppression(boxes[idx, :4], scores_all[idx], max_detections, nms_threshold)
-    idx = idx[keep]
+    if nms:                                                      # filter_detections.py:56-64
+        keep = non_max_suppression(boxes[idx, :4], scores_all[idx], max_detections, nms_threshold)
+        idx = idx[keep]
     sc = scores_all[idx]
     order = np.argsort(-sc, kind='stable')[:max_detections]      # tf.nn.top_k
     idx = idx[order]

@@ -58,10 +58,14 @@ def make_case(image_hw, batch, seed, logit_mean, logit_std):
     dims = ref_layers.RegressDims(mean=decode_np.DIM_MEAN.astype(F), std=decode_np.DIM_STD.astype(F)).call(regression_dim)
     outs = [ref_filter(boxes[b], dims[b], cls[b]) for b in range(batch)]
     det = [np.stack([np.asarray(o[k]) for o in outs]) for k in range(5)]
+    outs2 = [ref_filter(boxes[b], dims[b], cls[b], nms=False) for b in range(batch)]          # load_model(..., nms=False)
+    det2 = [np.stack([np.asarray(o[k]) for o in outs2]) for k in range(5)]
     return dict(image_hw=np.array(image_hw), anchors=anchors[0], logits=logits, classification=cls, regression=regression,
                 regression_dim=regression_dim, all_boxes=boxes.astype(F), all_dims=dims.astype(F),
                 boxes=det[0].astype(F), dimensions=det[1].astype(F), scores=det[2].astype(F),
-                labels=det[3].astype(np.int32), orientations=det[4].astype(np.int32))
+                labels=det[3].astype(np.int32), orientations=det[4].astype(np.int32),
+                nonms_boxes=det2[0].astype(F), nonms_dimensions=det2[1].astype(F), nonms_scores=det2[2].astype(F),
+                nonms_labels=det2[3].astype(np.int32), nonms_orientations=det2[4].astype(np.int32))
 
 
 def main():

@@ -36,6 +36,9 @@ def test_hip_decode_matches_reference_goldens(name, fused):
         assert got.dtype == g[key].dtype and helpers.bits_equal(got, g[key]), key
     cand = (np.maximum(g['classification'][..., :4], g['classification'][..., 4:]).max(-1) > np.float32(0.05)).sum(axis=1)
     assert np.array_equal(out[6], cand.astype(np.int32))
+    out = filter_detections(g['logits'], reg, g['regression_dim'], g['anchors'], fused_regression=fused, nms=False)
+    for got, key in zip(out[:5], ('boxes', 'dimensions', 'scores', 'labels', 'orientations')):
+        assert helpers.bits_equal(got, g['nonms_' + key]), 'nms=False ' + key
 
 
 @pytest.mark.parametrize('hw,batch,mean,std', [((96, 160), 3, -3.5, 1.0), ((128, 416), 2, -4.6, 0.8), ((402, 1333), 1, -4.6, 0.75)])
@@ -104,3 +107,22 @@ def test_hip_decode_large_k_prefix_and_fallback_paths():
         for got, want in zip(out[:5], ref):
             assert helpers.bits_equal(got[0], want)
         assert np.array_equal(out[5][0].astype(np.int64), ref_idx)
+
+
+def test_hip_decode_without_nms():
+    """ nms=False (load_model(..., nms=False)): score threshold + top-k only (filter_detections.py:56,159) """
+    rng = np.random.default_rng(31)
+    anchors = A.anchors_for_image((96, 160))
+    n = anchors.shape[0]
+    logits = rng.normal(-3.0, 1.0, size=(2, n, 8)).astype(np.float32)
+    reg = rng.normal(0, 1, size=(2, n, 12)).astype(np.float32)
+    dim = rng.normal(0, 1, size=(2, n, 3)).astype(np.float32)
+    cls = decode_np.sigmoid(logits)
+    boxes = decode_np.regress_boxes(np.broadcast_to(anchors[None], (2,) + anchors.shape), reg, cls)
+    dims = decode_np.regress_dims(dim)
+    out = filter_detections(logits, reg, dim, anchors, nms=False)
+    for b in range(2):
+        ref, ref_idx = decode_np.filter_detections(boxes[b], dims[b], cls[b], nms=False)
+        for got, want in zip(out[:5], ref):
+            assert helpers.bits_equal(got[b], want)
+        assert np.array_equal(out[5][b].astype(np.int64), ref_idx)

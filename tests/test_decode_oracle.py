@@ -33,6 +33,10 @@ def test_oracle_decode_matches_reference_goldens(name):
     det, _ = decode_np.detect(g['logits'], g['regression'], g['regression_dim'], anchors)
     for got, key in zip(det, ('boxes', 'dimensions', 'scores', 'labels', 'orientations')):
         assert got.dtype == g[key].dtype and np.array_equal(got, g[key]), key
+    for b in range(B):                                                  # nms=False variant (filter_detections.py:56)
+        out, _ = decode_np.filter_detections(boxes[b], decode_np.regress_dims(g['regression_dim'])[b], g['classification'][b], nms=False)
+        for got, key in zip(out, ('boxes', 'dimensions', 'scores', 'labels', 'orientations')):
+            assert np.array_equal(got, g['nonms_' + key][b]), key
 
 
 def test_goldens_cover_padding_empty_and_saturated_images():
