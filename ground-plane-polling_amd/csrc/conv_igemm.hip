@@ -568,6 +568,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
     if (d.tile_hint == 512 || (d.tile_hint == 0 && n_fits && big_blocks >= 512 && nk >= 8))
         return (d.reserved & 8) ? launch<DT, 256, 256, 2, 4, 2, false>(d, st) : launch<DT, 256, 256, 2, 4, 2, true>(d, st);
     if (d.tile_hint == 256) return launch<DT, 256, 128, 4, 2, 3, false>(d, st);
+    if (d.tile_hint == 64) return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
     return (d.reserved & 4) ? launch<DT, 128, 128, 2, 2, 2, true>(d, st) : launch<DT, 128, 128, 2, 2, 2, false>(d, st);
 }
 

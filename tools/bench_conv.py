@@ -43,6 +43,13 @@ def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False, 
 
 if __name__ == '__main__':
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    if len(sys.argv) > 2 and sys.argv[2] == 'stages':
+        for name, shp, cin, cout, k in (('res4 2a 1x1 1024->256', [(26, 84)], 1024, 256, 1), ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3),
+                                         ('res4 2c 1x1 256->1024', [(26, 84)], 256, 1024, 1), ('res3 2b 3x3 128->128', [(51, 167)], 128, 128, 3),
+                                         ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3), ('cls 3x3 256->256', PYR, 256, 256, 3)):
+            for tile in (128, 64):
+                bench('%s t%d' % (name, tile), B, shp, cin, cout, k, tile=tile)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'pipe':
         for rep in range(2):
             for tile in (128, 512):
