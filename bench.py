@@ -187,6 +187,7 @@ def main():
     # informational, outside the timed region and never `value`: the same step fed from HOST memory --
     # raw uint8 frames uploaded over PCIe, preprocessed on the GPU, 8 result arrays copied back
     pcie_rate = None
+    pcie_pipelined = None
     if rank == 0 and world == 1:
         frames = np.stack([synthetic.synthetic_image(seed=i) for i in range(B)])
         _, P_inv_s = synthetic.synthetic_calibration(1333.0 / 1242.0)
@@ -201,6 +202,15 @@ def main():
             model.predict_on_frames(frames, P_host, planes_host)
         torch.cuda.synchronize()
         pcie_rate = round(B * n_it / (time.perf_counter() - t1), 1)
+        from keras_retinanet_3D.utils.pipeline import FramePipeline
+        pipe = FramePipeline(model, depth=2)
+        list(pipe.run(iter([(frames, P_host, planes_host)] * 3)))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_it = 20
+        for _ in pipe.run(iter([(frames, P_host, planes_host)] * n_it)):
+            pass
+        pcie_pipelined = round(B * n_it / (time.perf_counter() - t1), 1)
 
     if rank == 0:
         total_images = world * B * args.steps
@@ -216,7 +226,8 @@ def main():
                        'candidates_per_image': [int(c) for c in counts], 'detections_rank0': dets,
                        'algorithmic_gflop_per_image': round(plan.flops / B / 1e9, 1),
                        'achieved_tflops_whole_path': round(plan.flops * args.steps / elapsed / 1e12, 1),
-                       'host_fed_images_per_s_incl_pcie_and_gpu_preprocessing': pcie_rate},
+                       'host_fed_images_per_s_incl_pcie_and_gpu_preprocessing': pcie_rate,
+                       'host_fed_images_per_s_pipelined_uploads': pcie_pipelined},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': traffic,
                          'traffic_unit': 'MB per launch at the L2<->fabric interface (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; '

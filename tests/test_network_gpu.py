@@ -166,3 +166,23 @@ def test_run_network_cli_on_the_gpu(tmp_path):
         assert np.all(np.diff(mat['scores'][0]) <= 0) and np.isfinite(mat['angles']).all()
         txt = (tmp_path / 'out' / 'synthetic:1234' / 'outputs' / 'kitti' / ('%06d.txt' % k)).read_text()
         assert txt.count('\n') == n and txt.startswith('Car -1 -1 ')
+
+
+def test_frame_pipeline_matches_synchronous_calls(model50):
+    from keras_retinanet_3D.utils.pipeline import FramePipeline
+    from keras_retinanet_3D.utils import image
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    scale = image.compute_resize_scale((375, 1242, 3))
+    _, P_inv = synthetic.synthetic_calibration(scale)
+    P_inv = np.tile(P_inv[None].astype(np.float32), (2, 1, 1))
+    batches = []
+    for k in range(5):
+        frames = (np.random.default_rng(k).integers(0, 2, size=(2, 375, 1242, 3)) * 255).astype(np.uint8)
+        batches.append((frames, P_inv, planes))
+    want = [model50.predict_on_frames(*b)[0] for b in batches]
+    got = list(FramePipeline(model50, depth=2).run(iter(batches)))
+    assert len(got) == 5
+    for (outs, sc), ref in zip(got, want):
+        assert sc == scale
+        for a, b in zip(outs, ref):
+            assert helpers.bits_equal(a, b) if a.dtype.kind == 'f' else np.array_equal(a, b)
