@@ -78,6 +78,7 @@ class Plan(object):
 
     def __init__(self):
         self.keep = []          # ctypes descriptors and torch buffers kept alive
+        self.io = {}            # conv op name -> (input FMaps, output FMaps, residual FMaps or None)
         self.ops = []           # (kind, tag, desc, name, flops)
         self.array = None
         self.flops = 0.0
@@ -163,6 +164,7 @@ class RetinaNet3D(object):
         d = C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
                         residuals=residuals, dtype=self.dtype, out_f32=out_f32, workspace=plan.workspace)
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d))
+        plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
         torch, dev, dt = self.torch, self.device, self.tdtype
@@ -187,9 +189,11 @@ class RetinaNet3D(object):
         d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
                      C.gpp_dtype(self.dtype), B, H, Wd)
         plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
+        plan.stem_out = stem
         H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
         x = fmap(H2, W2, 64)
         plan.add(OP_MAXPOOL, PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_dtype(self.dtype), B, H1, W1, 64, 0), 'pool1')
+        plan.pool_out = x
 
         # ---- bottleneck stages (keras_resnet bottleneck_2d: stride on the first 1x1).
         # A stage can be run chunk of images by chunk of images (GPP_STAGE_CHUNKS="2,4,8,8") to keep a chunk's
@@ -262,6 +266,7 @@ class RetinaNet3D(object):
         R6 = fmap(shapes[3][0], shapes[3][1], 512)
         plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * 2, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
                                    pix[3] * 512, C.gpp_dtype(self.dtype), B), 'C6_relu')
+        plan.relu_io = (P[3], R6)
         self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
                    pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]))
 
@@ -337,6 +342,10 @@ class RetinaNet3D(object):
         return self._plans[key]
 
     # ------------------------------------------------------------------ execution
+    def run_op(self, plan, index):
+        """ Enqueue ONE op of the plan (per-layer tests). """
+        hip.check(hip.lib().gpp_plan_run(ctypes.byref(plan.array, index * ctypes.sizeof(PlanOp)), 1, hip.stream_ptr(), None, 0), 'gpp_plan_run')
+
     def run_plan(self, plan, events=None):
         """ Enqueue the whole forward on the current stream (asynchronous). """
         if events is None and getattr(plan, 'graph', None) is not None:

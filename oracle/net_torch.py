@@ -71,6 +71,13 @@ class Net(object):
         self.backbone = backbone
         self.storage = storage
         self.q = _quantizer(storage)
+        self.trace = None            # when a dict: every layer output, {(layer name, pyramid level): NHWC array}
+        self._level = 0
+
+    def _rec(self, name, y):
+        if self.trace is not None:
+            self.trace[(name, self._level)] = y.permute(0, 2, 3, 1).contiguous().numpy()
+        return y
 
     # conv + frozen BN (+ ReLU); literal BN in float32 mode, folded + rounded weights in storage mode
     def conv_bn(self, x, conv, bn, stride=1, pad=None, relu=True, add=None, quant_weights=True, f16_operands=False):
@@ -93,7 +100,7 @@ class Net(object):
             y = y + add
         if relu:
             y = torch.relu(y)
-        return self.q(y)
+        return self._rec(conv, self.q(y))
 
     def conv_bias(self, x, name, stride=1, relu=False, add=None, store=True):
         k = torch.as_tensor(self.w[name + '/kernel'])
@@ -103,7 +110,7 @@ class Net(object):
             y = y + add
         if relu:
             y = torch.relu(y)
-        return self.q(y) if store else y
+        return self._rec(name, self.q(y) if store else y)
 
     def block_name(self, stage, block):
         if block > 0 and NUMERICAL[self.backbone][stage]:
@@ -114,7 +121,7 @@ class Net(object):
         x = self.conv_bn(x, 'conv1', 'bn_conv1', stride=2, pad=3, quant_weights=False, f16_operands=True)
         ph = _same_pad(x.shape[2], 3, 2)
         pw = _same_pad(x.shape[3], 3, 2)
-        x = F.max_pool2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf')), 3, 2)
+        x = self._rec('pool1', F.max_pool2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf')), 3, 2))
         outs = []
         for stage, n_blocks in enumerate(BLOCKS[self.backbone]):
             for block in range(n_blocks):
@@ -141,7 +148,7 @@ class Net(object):
         P3 = self.conv_bias(C3, 'C3_reduced', add=P4_up)
         P3 = self.conv_bias(P3, 'P3')
         P6 = self.conv_bias(C5, 'P6', stride=2)
-        P7 = self.conv_bias(self.q(torch.relu(P6)), 'P7', stride=2)
+        P7 = self.conv_bias(self._rec('C6_relu', self.q(torch.relu(P6))), 'P7', stride=2)
         return [P3, P4, P5, P6, P7]
 
     @staticmethod
@@ -152,7 +159,8 @@ class Net(object):
     def heads(self, features):
         """ models/retinanet.py:24-167 applied per level and concatenated along axis 1 (:257-281) """
         reg, dim, cls = [], [], []
-        for f in features:
+        for level, f in enumerate(features):
+            self._level = level
             y = f
             for i in range(4):
                 y = self.conv_bias(y, 'pyramid_regression_{}'.format(i), relu=True)
@@ -167,22 +175,26 @@ class Net(object):
             for i in range(4):
                 y = self.conv_bias(y, 'pyramid_classification_{}'.format(i), relu=True)
             cls.append(self._rows(self.conv_bias(y, 'pyramid_classification', store=False), 8))
+        self._level = 0
         return torch.cat(reg, dim=1), torch.cat(dim, dim=1), torch.cat(cls, dim=1)
 
-    def forward(self, images_nhwc, keep_features=False):
+    def forward(self, images_nhwc, keep_features=False, trace=False):
         """ images (B, H, W, 3) float32 BGR mean-subtracted -> dict of NumPy arrays:
         regression (B, A, 12), regression_dim (B, A, 3), classification_logits (B, A, 8) """
+        self.trace = {} if trace else None
         with torch.no_grad():
             x = torch.as_tensor(np.ascontiguousarray(images_nhwc, dtype=np.float32)).permute(0, 3, 1, 2)
             C2, C3, C4, C5 = self.resnet(x)
             feats = self.fpn(C3, C4, C5)
             reg, dim, cls = self.heads(feats)
         out = {'regression': reg.numpy(), 'regression_dim': dim.numpy(), 'classification_logits': cls.numpy()}
+        if trace:
+            out['trace'] = self.trace
         if keep_features:
             for name, t in zip(('C2', 'C3', 'C4', 'C5', 'P3', 'P4', 'P5', 'P6', 'P7'), [C2, C3, C4, C5] + feats):
                 out[name] = t.permute(0, 2, 3, 1).contiguous().numpy()
         return out
 
 
-def forward(weights, images_nhwc, backbone='resnet50', storage=None, keep_features=False):
-    return Net(weights, backbone, storage).forward(images_nhwc, keep_features=keep_features)
+def forward(weights, images_nhwc, backbone='resnet50', storage=None, keep_features=False, trace=False):
+    return Net(weights, backbone, storage).forward(images_nhwc, keep_features=keep_features, trace=trace)
