@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;   // LDS-DMA instructions per wave per stage
     constexpr int PER_STAGE = A_IT + B_IT;
     constexpr int PF = STAGES - 1;                       // K-steps in flight ahead of the one computed
-    static_assert(MF % 2 == 0 && MF >= 2 && NF >= 1 && A_IT >= 1 && B_IT >= 1, "tile / wave shape");
+    static_assert(MF >= 1 && NF >= 1 && A_IT >= 1 && B_IT >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WM) == 0, "tile / wave shape");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -297,13 +297,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
         //   phase 0:  MFMA(kk=0 of k)  ||  LDS reads of kk=1 of k
         //   wait stage k+1 landed, lgkmcnt(0), s_barrier      (everyone is done reading buffer k&1)
         //   phase 1:  MFMA(kk=1 of k)  ||  LDS-DMA of stage k+2 into buffer k&1  ||  LDS reads of kk=0 of k+1
-        // Each phase is cut into MF groups {1-2 LDS-DMA, 1-2 ds_read_b128, NF MFMA} pinned with
+        // Each phase is cut into MF groups {PER_STAGE/MF LDS-DMA, 1-2 ds_read_b128, NF MFMA} pinned with
         // sched_barrier, so the ~100-cycle issue cost of every LDS-DMA and the LDS read latency sit
         // under matrix-pipe work instead of in front of it.  In the tail the DMA goes through a
         // zero-length descriptor (dropped by the range check) and the look-ahead reads hit a buffer
         // nobody uses: no branches inside the interleaved region.
-        static_assert(STAGES == 2 && PER_STAGE % MF == 0, "pipelined loop: two buffers, loads divide over the groups");
-        constexpr int LPG = PER_STAGE / MF;              // LDS-DMA instructions per group
+        static_assert(STAGES == 2, "pipelined loop: two buffers");
         const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, 0, 0x00020000);
         auto issue_one = [&](int idx, int buf, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int so_a, int so_w) {
             unsigned char* sa = smem + buf * STAGE + wave * A_IT * 8 * kRowBytes;
@@ -344,7 +343,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
 #pragma unroll
             for (int g = 0; g < MF; ++g) {
                 a1[g] = *(const vec8*)(scur + a_rd[1] + g * 16 * kRowBytes);
-                if (g < NF) b1[g < NF ? g : 0] = *(const vec8*)(scur + b_rd[1] + g * 16 * kRowBytes);
+#pragma unroll
+                for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) b1[j] = *(const vec8*)(scur + b_rd[1] + j * 16 * kRowBytes);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[g][j] = E::mfma(b0[j], a0[g], acc[g][j]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -361,9 +361,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
 #pragma unroll
             for (int g = 0; g < MF; ++g) {
 #pragma unroll
-                for (int q = 0; q < LPG; ++q) issue_one(g * LPG + q, cur, ra, rw, so_a, so_w);
+                for (int idx = g * PER_STAGE / MF; idx < (g + 1) * PER_STAGE / MF; ++idx) issue_one(idx, cur, ra, rw, so_a, so_w);
                 a0[g] = *(const vec8*)(snxt + a_rd[0] + g * 16 * kRowBytes);
-                if (g < NF) b0[g < NF ? g : 0] = *(const vec8*)(snxt + b_rd[0] + g * 16 * kRowBytes);
+#pragma unroll
+                for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) b0[j] = *(const vec8*)(snxt + b_rd[0] + j * 16 * kRowBytes);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) acc[g][j] = E::mfma(b1[j], a1[g], acc[g][j]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -554,22 +555,43 @@ int launch(gpp_conv_desc& d, hipStream_t st)
 template <int DT>
 int dispatch(gpp_conv_desc& d, hipStream_t st)
 {
-    const bool narrow = d.C_out <= 64 || (d.C_out % 128 != 0 && d.C_out % 128 <= 64);
+    switch (d.tile_hint) {               // explicit choices (BM*1000 + BN, or the legacy codes): what the host-side autotuner hands in
+        case 64:
+        case 128064: return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
+        case 64064: return launch<DT, 64, 64, 2, 2, 2, false>(d, st);
+        case 96064: return launch<DT, 96, 64, 2, 2, 2, false>(d, st);
+        case 160064: return launch<DT, 160, 64, 2, 2, 2, false>(d, st);
+        case 192064: return launch<DT, 192, 64, 2, 2, 2, false>(d, st);
+        case 64128: return launch<DT, 64, 128, 2, 2, 2, false>(d, st);
+        case 96128: return launch<DT, 96, 128, 2, 2, 2, false>(d, st);
+        case 128:
+        case 128128: return (d.reserved & 4) ? launch<DT, 128, 128, 2, 2, 2, true>(d, st) : launch<DT, 128, 128, 2, 2, 2, false>(d, st);
+        case 160128: return launch<DT, 160, 128, 2, 2, 2, false>(d, st);
+        case 192128: return launch<DT, 192, 128, 2, 2, 2, false>(d, st);
+        case 224128: return launch<DT, 224, 128, 2, 2, 2, false>(d, st);
+        case 256: return launch<DT, 256, 128, 4, 2, 3, false>(d, st);          // 3-deep ring, experiments only
+        case 1128128: return launch<DT, 128, 128, 2, 2, 2, true>(d, st);        // 1000000 + ...: the pipelined main loop
+        case 1192128: return launch<DT, 192, 128, 2, 2, 2, true>(d, st);
+        case 1128256: return launch<DT, 128, 256, 2, 4, 2, true>(d, st);
+        case 1192256: return launch<DT, 192, 256, 2, 4, 2, true>(d, st);
+        case 512:
+        case 256256: return (d.reserved & 8) ? launch<DT, 256, 256, 2, 4, 2, false>(d, st) : launch<DT, 256, 256, 2, 4, 2, true>(d, st);
+        case 0: break;
+        default: return GPP_ERR_BAD_ARG;
+    }
+    // ---- default heuristic (tile_hint == 0)
+    if (d.C_out <= 64 || (d.C_out % 128 != 0 && d.C_out % 128 <= 64)) return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
+    // 256x256 tile (8 wavefronts, 1 workgroup / CU) halves the L2 -> LDS traffic per FLOP; it pays
+    // when there are enough tiles for two rounds over the 256 CUs and enough K-steps to amortise
+    // its longer prologue/epilogue
     int64_t rows = 0;
     for (int g = 0; g < d.n_groups; ++g) rows += (int64_t)d.batch * d.groups[g].H_out * d.groups[g].W_out;
     const int nk = d.KH * d.KW * (d.C_in / 64);
-    if (narrow) return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
-    // 256x256 tile (8 wavefronts, 1 workgroup / CU) halves the L2 -> LDS traffic per FLOP; it pays
-    // when there are enough tiles for two rounds over the 256 CUs and enough K-steps to amortise
-    // its longer prologue/epilogue.  (256x128 with a 3-deep ring is kept for experiments only.)
     const int n256 = (d.C_out + 255) / 256;
     const int64_t big_blocks = ((rows + 255) / 256) * n256;
     const bool n_fits = d.C_out >= 256 && n256 * 256 * 7 <= d.C_out * 8;      // at most 1/8 of the N tiles is padding
-    if (d.tile_hint == 512 || (d.tile_hint == 0 && n_fits && big_blocks >= 512 && nk >= 8))
-        return (d.reserved & 8) ? launch<DT, 256, 256, 2, 4, 2, false>(d, st) : launch<DT, 256, 256, 2, 4, 2, true>(d, st);
-    if (d.tile_hint == 256) return launch<DT, 256, 128, 4, 2, 3, false>(d, st);
-    if (d.tile_hint == 64) return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
-    return (d.reserved & 4) ? launch<DT, 128, 128, 2, 2, 2, true>(d, st) : launch<DT, 128, 128, 2, 2, 2, false>(d, st);
+    if (n_fits && big_blocks >= 512 && nk >= 8) return launch<DT, 256, 256, 2, 4, 2, true>(d, st);
+    return launch<DT, 128, 128, 2, 2, 2, false>(d, st);
 }
 
 int validate(const gpp_conv_desc& d)
@@ -619,4 +641,71 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
     if (rc != GPP_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     return d.dtype == GPP_BF16 ? dispatch<GPP_BF16>(d, st) : dispatch<GPP_F16>(d, st);
+}
+
+// Pick the fastest tile / split-K configuration for one layer by timing the candidates on the
+// device (the layer is idempotent: it only rewrites its own output).  The tile-count arithmetic
+// (how many workgroups land on 256 CUs, in how many rounds) decides most mid-sized layers and is
+// not worth modelling: measure.  Writes the winner into desc->tile_hint / desc->split_k.
+extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* best_us)
+{
+    if (!desc || iters < 1) return GPP_ERR_BAD_ARG;
+    static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
+                                 1128128, 1192128, 1128256, 1192256, 256256};
+    static const int kSplits[] = {1, 2, 3, 4, 6, 8};
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
+    const int tile_in = desc->tile_hint, split_in = desc->split_k;
+    const int nk = desc->KH * desc->KW * (desc->C_in / 64);
+    int64_t rows = 0;
+    for (int g = 0; g < desc->n_groups; ++g) rows += (int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out;
+    float best = 1e30f;
+    int best_tile = tile_in, best_split = split_in, rc = GPP_OK;
+    auto time_one = [&](int tile, int split, float* us) -> int {
+        desc->tile_hint = tile;
+        desc->split_k = split;
+        int r = gpp_conv2d_igemm(desc, stream);                      // warm-up (and validity of this choice)
+        if (r != GPP_OK) return r;
+        float t_best = 1e30f;
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(e0, st);
+            for (int i = 0; i < iters; ++i) (void)gpp_conv2d_igemm(desc, stream);
+            (void)hipEventRecord(e1, st);
+            hipError_t s = hipEventSynchronize(e1);
+            if (s != hipSuccess) return (int)s;
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            t_best = ms < t_best ? ms : t_best;
+        }
+        *us = t_best * 1000.0f / iters;
+        return GPP_OK;
+    };
+    for (int tile : kTiles) {
+        const int bn = tile % 1000 ? tile % 1000 : 128, bm = tile ? (tile / 1000) % 1000 : 128;
+        if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
+        if (bn == 256 && (desc->C_out < 192 || rows < 256 * 128)) continue;
+        if (tile > 1000000 && nk < 4) continue;                      // the pipelined loop needs a few K-steps to pay
+        float us = 0.0f;
+        int r = time_one(tile, tile == 0 ? split_in : 1, &us);
+        if (r != GPP_OK) { if (tile == 0) { rc = r; break; } continue; }
+        if (us < best) { best = us; best_tile = tile; best_split = tile == 0 ? split_in : 1; }
+        if (tile == 0 || bn == 256 || !desc->partial) continue;
+        const int64_t blocks = ((rows + bm - 1) / bm) * ((desc->C_out + bn - 1) / bn);
+        if (blocks >= 512 || nk < 16) continue;                      // split-K only for under-filled deep-K layers
+        for (int split : kSplits) {
+            if (split == 1 || nk / split < 8) continue;
+            // a split changes the summation order: take it only for a clear (> 3 %) win
+            if (time_one(tile, split, &us) == GPP_OK && us < 0.97f * best) { best = us; best_tile = tile; best_split = split; }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    desc->tile_hint = rc == GPP_OK ? best_tile : tile_in;
+    desc->split_k = rc == GPP_OK ? best_split : split_in;
+    if (best_us) *best_us = best;
+    return rc;
 }

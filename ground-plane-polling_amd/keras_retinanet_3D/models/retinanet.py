@@ -25,6 +25,8 @@ HBM layout
 """
 
 import ctypes
+import json
+import os
 
 import numpy as np
 
@@ -116,6 +118,8 @@ class RetinaNet3D(object):
         self.torch = torch
         self._plans = {}
         self._anchors = {}
+        self._tuned = {}             # (layer, B, H, W) -> (tile_hint, split_k, us): see _autotune
+        self._load_tune_cache()
         self._upload(weights)
         self.tag_names = []          # filled by the plan builder: names of event-tagged ops
 
@@ -199,7 +203,6 @@ class RetinaNet3D(object):
         # A stage can be run chunk of images by chunk of images (GPP_STAGE_CHUNKS="2,4,8,8") to keep a chunk's
         # working set inside the 256 MiB Infinity Cache; measured on MI355X at B = 8 this LOSES 1-6 % (the smaller
         # launches cost more than the on-die re-reads save), so the default is the whole batch per launch.
-        import os
         env_chunks = os.environ.get('GPP_STAGE_CHUNKS')
 
         def sub(fm, c0, nb):
@@ -333,7 +336,68 @@ class RetinaNet3D(object):
         plan.add(OP_POLL, pd, 'fit_road_planes', flops=162.0 * B * D * n_planes)
         plan.finalize()
         plan.tagged = [name for _, tag, _, name, _ in plan.ops if tag]
+        if os.environ.get('GPP_AUTOTUNE', '1') != '0':
+            self._autotune(plan)
         return plan
+
+    # ------------------------------------------------------------------ per-layer tile selection
+    def _tune_cache_path(self):
+        return os.environ.get('GPP_TUNE_CACHE')
+
+    def _load_tune_cache(self):
+        path = self._tune_cache_path()
+        if path and os.path.exists(path):
+            with open(path) as f:
+                for key, val in json.load(f).items():
+                    bb, dt, name, b, h, w = key.split('|')
+                    if bb == self.backbone_name and dt == self.dtype:
+                        self._tuned[(name, int(b), int(h), int(w))] = tuple(val)
+
+    def _save_tune_cache(self):
+        path = self._tune_cache_path()
+        if not path:
+            return
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        for (name, b, h, w), val in self._tuned.items():
+            data['|'.join([self.backbone_name, self.dtype, name, str(b), str(h), str(w)])] = list(val)
+        with open(path, 'w') as f:
+            json.dump(data, f, indent=0, sort_keys=True)
+
+    def _autotune(self, plan):
+        """ Choose the block tile and split-K of every conv layer of this plan by timing the candidates on
+        the device (gpp_conv2d_autotune), layer by layer on realistic activations (a noise frame pushed
+        through the layers before).  Whether a layer's tile grid fills the 256 CUs in 1.07 or 0.95 rounds
+        decides its time by up to 1.5x and is cheap to measure.  Tile choice never changes results; split-K
+        changes the float32 summation order (last bits), so decisions are remembered per (layer, batch,
+        image size) -- every plan of a model makes the same ones -- and can be persisted with
+        GPP_TUNE_CACHE=<file.json>.  GPP_AUTOTUNE=0 keeps the library heuristic. """
+        torch = self.torch
+        B, H, Wd = plan.shape[:3]
+        plan.images.uniform_(-120.0, 130.0)
+        best = ctypes.c_float(0.0)
+        fresh = False
+        plan.tuning = {}
+        for index, (kind, _, desc, name, flops) in enumerate(plan.ops):
+            if kind in (OP_DETECT, OP_POLL):
+                continue
+            self.run_op(plan, index)
+            if kind != OP_CONV:
+                continue
+            key = (name, B, H, Wd)
+            if key not in self._tuned:
+                iters = 4 if flops > 5e10 else 16
+                hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(desc), iters, hip.stream_ptr(), ctypes.byref(best)),
+                          'gpp_conv2d_autotune')
+                self._tuned[key] = (int(desc.tile_hint), int(desc.split_k), round(float(best.value), 2))
+                fresh = True
+            desc.tile_hint, desc.split_k = self._tuned[key][0], self._tuned[key][1]
+            plan.tuning[name] = self._tuned[key]
+        torch.cuda.synchronize()
+        if fresh:
+            self._save_tune_cache()
 
     def plan_for(self, B, H, Wd, n_planes, planes_batched):
         key = (int(B), int(H), int(Wd), int(n_planes), bool(planes_batched))

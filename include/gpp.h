@@ -132,7 +132,8 @@ typedef struct gpp_conv_desc {
     int32_t weight_rows;
     int32_t relu;
     int32_t n_groups;
-    int32_t tile_hint;              /* 0 = library chooses the tile; 128 / 256 force the block-tile height (tuning, tests) */
+    int32_t tile_hint;              /* 0 = library heuristic; BM*1000 + BN forces a block tile (64..224 x 64/128, 256256);
+                                       legacy codes 64 / 128 / 256 / 512; anything else: GPP_ERR_BAD_ARG.  See gpp_conv2d_autotune */
     int32_t reserved;
     int32_t in_bytes, weight_bytes; /* filled in by the library: extents for the range-checked buffer loads */
     void* partial;                  /* optional split-K workspace (float32 partial tiles), 16-byte aligned; NULL = never split */
@@ -143,6 +144,11 @@ typedef struct gpp_conv_desc {
 } gpp_conv_desc;
 
 int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream);
+
+/* Time the tile / split-K candidates of this layer on the device (iters launches each; the layer only rewrites its own
+   output) and store the fastest in desc->tile_hint / desc->split_k.  best_us (optional): its time per launch.
+   Synchronises the stream.  Results do not depend on the tile choice; they depend on split_k only in the last bits. */
+int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* best_us);
 
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);

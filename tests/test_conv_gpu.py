@@ -5,11 +5,14 @@ PyTorch float32 reference of the same op on the CPU.  Inputs/weights are rounded
 final rounding of the output to 16 bits:  |err| <= 2^-8 * |ref| + 1e-3 (bf16), 2^-10 (f16),
 1e-4 relative for float32 outputs.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
+from keras_retinanet_3D.backend import hip
 from keras_retinanet_3D.layers import conv as C
 
 pytestmark = pytest.mark.gpu
@@ -168,3 +171,76 @@ def test_split_k_matches_torch_fp32(case, split):
     assert bool((err <= eps * ref.abs() + 1e-3).all()), err.max().item()
     C.run_conv(d)                                              # deterministic: fixed summation order over the splits
     assert torch.equal(out.buf.float().cpu(), got)
+
+
+ALL_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
+             1128128, 1192128, 1128256, 1192256, 256256]
+
+
+def _layer(name, dtype='bf16', workspace=False):
+    """ one CASES layer on the device: (descriptor factory, output map, float32 reference) """
+    _, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, out_f32 = [c for c in CASES if c[0] == name][0]
+    g = torch.Generator().manual_seed(len(name))
+    tdt = C.torch_dtype(dtype)
+    dev = torch.device('cuda')
+    x = torch.randn((B, H, W, Cin), generator=g).to(tdt)
+    k = (torch.randn((K, K, Cin, Cout), generator=g) * (2.0 / (K * K * Cin)) ** 0.5).to(tdt)
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    if pad is None:
+        oh, pt = C.same_pad(H, K, stride)
+        ow, pl = C.same_pad(W, K, stride)
+    else:
+        pt, pl = pad
+        oh, ow = out_hw if out_hw else (H, W)
+    res = None
+    if resmode == 'same':
+        res = torch.randn((B, oh, ow, Cout), generator=g).to(tdt)
+    elif resmode is not None:
+        res = torch.randn((B, resmode[0], resmode[1], Cout), generator=g).to(tdt)
+    ref = reference(x.float(), k.float(), bias, stride, pt, pl, oh, ow, relu, None if res is None else res.float())
+    xin = C.FMap(x.to(dev).contiguous(), B, H, W, Cin)
+    out = C.FMap.empty(B, oh, ow, Cout, torch.float32 if out_f32 else tdt, dev)
+    w = C.pack_weight(k.float().numpy(), dtype, dev)
+    rmap = None if res is None else [C.FMap(res.to(dev).contiguous(), B, res.shape[1], res.shape[2], Cout)]
+    ws = torch.empty((32 << 20,), dtype=torch.uint8, device=dev) if workspace else None
+    keep = (xin, w, rmap, ws, bias.to(dev))
+
+    def make(tile, split_k=1):
+        return C.conv_desc([xin], [out], w, keep[4], K, K, Cin, Cout, stride=stride, pad=(pt, pl), relu=relu,
+                           residuals=rmap, dtype=dtype, out_f32=out_f32, tile_hint=tile, workspace=ws, split_k=split_k)
+    return make, out, ref, (2.0 ** -8 if dtype == 'bf16' else 2.0 ** -10) if not out_f32 else 1e-4
+
+
+@pytest.mark.parametrize('case', ['3x3_wide', '1x1_res_up_nonint', 'head_out144_f32', '3x3_s2_tfsame', 'deepK'])
+def test_every_tile_gives_identical_results(case):
+    """ The block tile only changes which workgroup computes an output, never the order of its
+    K summation: every explicit tile code must reproduce the default bit for bit (and match torch). """
+    make, out, ref, eps = _layer(case)
+    out.buf.fill_(float('nan'))
+    C.run_conv(make(128128))
+    base = out.buf.float().cpu()
+    assert bool(((base - ref).abs() <= eps * ref.abs() + 1e-3).all())
+    for tile in ALL_TILES:
+        out.buf.fill_(float('nan'))
+        C.run_conv(make(tile))
+        assert torch.equal(out.buf.float().cpu(), base), tile
+
+
+def test_unknown_tile_code_is_rejected():
+    make, _, _, _ = _layer('3x3')
+    rc = hip.lib().gpp_conv2d_igemm(ctypes.byref(make(12345)), hip.stream_ptr())
+    assert rc == -1
+
+
+@pytest.mark.parametrize('case', ['3x3_wide', 'deepK', 'bottleneck_2c'])
+def test_autotune_picks_a_valid_configuration(case):
+    make, out, ref, eps = _layer(case, workspace=True)
+    d = make(0, split_k=0)
+    best = ctypes.c_float(-1.0)
+    hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(d), 3, hip.stream_ptr(), ctypes.byref(best)), 'gpp_conv2d_autotune')
+    assert (d.tile_hint == 0 or d.tile_hint in ALL_TILES) and 0 <= d.split_k <= 8 and 0.0 < best.value < 1e5
+    out.buf.fill_(float('nan'))
+    C.run_conv(d)
+    got = out.buf.float().cpu()
+    assert bool(((got - ref).abs() <= eps * ref.abs() + 1e-3).all())
+    assert hip.lib().gpp_conv2d_autotune(None, 3, hip.stream_ptr(), None) == -1

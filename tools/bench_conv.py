@@ -12,7 +12,7 @@ from keras_retinanet_3D.layers import conv as C  # noqa: E402
 PYR = [(51, 167), (26, 84), (13, 42), (7, 21), (4, 11)]
 
 
-def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False, tile=0, diag=0):
+def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False, tile=0, diag=0, residual=False):
     dev = torch.device('cuda')
     tdt = C.torch_dtype(dtype)
     total = sum(h * w for h, w in shapes)
@@ -25,7 +25,15 @@ def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False, 
         ins.append(C.FMap(x, B, h, wd, Cin, off=off * Cin, bstride=total * Cin))
         outs.append(C.FMap(o, B, h, wd, Cout, off=off * Cout, bstride=total * Cout))
         off += h * wd
-    d = C.conv_desc(ins, outs, w, bias, K, K, Cin, Cout, pad=(K // 2, K // 2), relu=True, dtype=dtype, out_f32=out_f32, tile_hint=tile, diag=diag)
+    res = None
+    if residual:
+        r = (torch.randn((B, total, Cout), device=dev) * 0.5).to(tdt)
+        res, off = [], 0
+        for h, wd in shapes:
+            res.append(C.FMap(r, B, h, wd, Cout, off=off * Cout, bstride=total * Cout))
+            off += h * wd
+    d = C.conv_desc(ins, outs, w, bias, K, K, Cin, Cout, pad=(K // 2, K // 2), relu=True, dtype=dtype, out_f32=out_f32, tile_hint=tile, diag=diag,
+                    residuals=res)
     for _ in range(3):
         C.run_conv(d)
     torch.cuda.synchronize()
@@ -37,7 +45,8 @@ def bench(name, B, shapes, Cin, Cout, K, dtype='bf16', iters=20, out_f32=False, 
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = C.conv_flops(d)
-    print('{:28s} {:8.3f} ms  {:8.1f} TFLOP/s  ({:.1f} GFLOP)'.format(name, ms, fl / ms / 1e9, fl / 1e9))
+    nbytes = B * total * (Cin + Cout * (2 if residual else 1)) * 2 + K * K * Cin * Cout * 2
+    print('{:28s} {:8.3f} ms  {:8.1f} TFLOP/s  ({:.1f} GFLOP)  {:6.2f} TB/s algorithmic'.format(name, ms, fl / ms / 1e9, fl / 1e9, nbytes / ms / 1e9))
     return ms
 
 
@@ -46,9 +55,26 @@ if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[2] == 'stages':
         for name, shp, cin, cout, k in (('res4 2a 1x1 1024->256', [(26, 84)], 1024, 256, 1), ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3),
                                          ('res4 2c 1x1 256->1024', [(26, 84)], 256, 1024, 1), ('res3 2b 3x3 128->128', [(51, 167)], 128, 128, 3),
-                                         ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3), ('cls 3x3 256->256', PYR, 256, 256, 3)):
-            for tile in (128, 64):
+                                         ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3), ('res5 2c 1x1 512->2048', [(13, 42)], 512, 2048, 1),
+                                         ('P4 3x3 512->512', [(26, 84)], 512, 512, 3), ('cls 3x3 256->256', PYR, 256, 256, 3)):
+            for tile in (128, 64, 96, 160, 192):
                 bench('%s t%d' % (name, tile), B, shp, cin, cout, k, tile=tile)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'big':
+        for rep in range(2):
+            for tile in (512, 128):
+                bench('reg 3x3 512->512 t%d' % tile, B, PYR, 512, 512, 3, tile=tile)
+                bench('towers_0 3x3 512->896 t%d' % tile, B, PYR, 512, 896, 3, tile=tile)
+                bench('cls 3x3 256->256 t%d' % tile, B, PYR, 256, 256, 3, tile=tile)
+                bench('C3_reduced 1x1 512->512 t%d' % tile, B, [(51, 167)], 512, 512, 1, tile=tile)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'hbm':
+        for name, shp, cin, cout, k, res in (('res2 2a 1x1 256->64', [(101, 334)], 256, 64, 1, False), ('res2 2b 3x3 64->64', [(101, 334)], 64, 64, 3, False),
+                                              ('res2 2c 1x1 64->256 +res', [(101, 334)], 64, 256, 1, True), ('res2 br1 1x1 64->256', [(101, 334)], 64, 256, 1, False),
+                                              ('res3 2a 1x1 512->128', [(51, 167)], 512, 128, 1, False), ('res3 2b 3x3 128->128', [(51, 167)], 128, 128, 3, False),
+                                              ('res3 2c 1x1 128->512 +res', [(51, 167)], 128, 512, 1, True)):
+            for tile in (64, 128, 512):
+                bench('%s t%d' % (name, tile), B, shp, cin, cout, k, tile=tile, residual=res)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'pipe':
         for rep in range(2):
