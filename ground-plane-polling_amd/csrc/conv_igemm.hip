@@ -496,6 +496,234 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const gpp_conv_desc 
     finish8<DT>(d, v, n, ra.obase, d.residual ? (const scalar*)d.residual + ra.rbase : nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused tail of a ResNet bottleneck: y = relu(W2 * relu(W1 (*) a + b1) + b2 + shortcut), i.e. the
+// 3x3 conv "branch2b" (CMID -> CMID, stride 1, pad 1) and the 1x1 conv "branch2c" (CMID -> 4*CMID,
+// + residual + ReLU) in one launch.  The BM x CMID tile of the intermediate never leaves the CU: it
+// goes accumulators -> (bias, ReLU, round to 16 bit exactly as the unfused layer would store it) ->
+// LDS in the A-operand layout, and is multiplied there by W2 in 128-wide output tiles.  Saves one
+// write + one read of the intermediate map (2 x 34.5 MB per res2 block at B = 8) on layers that are
+// HBM-bound; results are bit-identical to the two separate launches (same K order, same rounding).
+// d1 = descriptor of the 3x3 layer (its `out` is not written), d2 = descriptor of the 1x1 layer.
+template <int DT, int BM, int CMID>
+__global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2)
+{
+    using E = Elem<DT>;
+    using vec8 = typename E::vec8;
+    using scalar = typename E::scalar;
+    constexpr int WM = 2, WN = 2, NW = 4;
+    constexpr int MF = BM / WM / 16, NF1 = CMID / WN / 16, NF2 = 4;       // phase 2: BM x 128 output tiles
+    constexpr int KC = CMID / 64;                                          // 64-channel chunks of the intermediate
+    constexpr int A_BYTES = BM * kRowBytes, B_BYTES = CMID * kRowBytes, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_IT = BM / 8 / NW, B_IT = CMID / 8 / NW, PER_STAGE = A_IT + B_IT;
+    constexpr int T_BYTES = KC * A_BYTES;                                  // intermediate tile, A-operand layout
+    constexpr int W2_IT = 128 / 8 / NW;                                    // LDS-DMA per wave per chunk of a W2 tile
+    static_assert(BM % 32 == 0 && (CMID == 64 || CMID == 128), "tile shape");
+    static_assert(T_BYTES + KC * 128 * kRowBytes <= 2 * STAGE, "phase-2 buffers alias the phase-1 ring");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int mt = xcd_remap(blockIdx.x, gridDim.x);
+    const gpp_conv_group& G1 = d1.groups[0];
+    const gpp_conv_group& G2 = d2.groups[0];
+    const int H = G1.H_out, W = G1.W_out, HW = H * W;
+    const int Mg = d1.batch * HW;
+    const int m0 = mt * BM;
+
+    // ---- phase 1: 3x3 conv, the main loop of conv_igemm_kernel with BN = CMID
+    const int srow = lane >> 3;
+    const int gchunk = (lane & 7) ^ srow;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d1.in, 0, d1.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d1.weight, 0, d1.weight_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d2.weight, 0, d2.weight_bytes, 0x00020000);
+    int a_base[A_IT], a_mask[A_IT], a_voff[A_IT];
+    const int pitch2 = d1.in_pitch * 2;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + (wave * A_IT + i) * 8 + srow;
+        a_mask[i] = 0;
+        a_base[i] = 0;
+        if (m < Mg) {
+            const int b = m / HW, p = m - b * HW;
+            const int oy = p / W, ox = p - oy * W;
+            const int iy0 = oy - 1, ix0 = ox - 1;
+            int mask = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) mask |= (((unsigned)(iy0 + k) < (unsigned)H) << k) | (((unsigned)(ix0 + k) < (unsigned)W) << (8 + k));
+            a_mask[i] = mask;
+            a_base[i] = (int)((G1.in_off + (int64_t)b * G1.in_bstride) * 2) + gchunk * 16 + (iy0 * W + ix0) * pitch2;
+        }
+    }
+    constexpr int Ktot1 = 9 * CMID;
+    int w_voff[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) w_voff[i] = ((wave * B_IT + i) * 8 + srow) * Ktot1 * 2 + gchunk * 16;
+    auto set_tap = [&](int kh, int kw) {
+        const int delta = (kh * W + kw) * pitch2;
+        const int need = (1 << kh) | (1 << (8 + kw));
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) a_voff[i] = ((a_mask[i] & need) == need) ? a_base[i] + delta : kOutOfRange;
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_rd[2], b1_rd[2], b2_rd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = ((kk * 4 + fq) ^ (frow & 7)) << 4;
+        a_rd[kk] = (wm * (BM / WM) + frow) * kRowBytes + sw;
+        b1_rd[kk] = A_BYTES + (wn * (CMID / WN) + frow) * kRowBytes + sw;
+        b2_rd[kk] = T_BYTES + (wn * 64 + frow) * kRowBytes + sw;
+    }
+    f32x4 acc1[MF][NF1];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF1; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int nk = 9 * KC;
+    int cc = 0, kw = 0, kh = 0, issued = 0, ibuf = 0;
+    set_tap(0, 0);
+    auto issue_next = [&]() {
+        unsigned char* sa = smem + ibuf * STAGE + wave * A_IT * 8 * kRowBytes;
+        unsigned char* sb = smem + ibuf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) glds16(in_rsrc, a_voff[i], cc * kRowBytes, sa + i * 8 * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16(w1_rsrc, w_voff[i], issued * kRowBytes, sb + i * 8 * kRowBytes);
+        if (++kw == 3) {
+            kw = 0;
+            if (++kh == 3) { kh = 0; ++cc; }
+        }
+        set_tap(kh, kw);
+        ++issued;
+        ibuf ^= 1;
+    };
+    issue_next();
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < nk) issue_next();
+        const unsigned char* sbase = smem + (ks & 1) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            vec8 af[MF], bfr[NF1];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const vec8*)(sbase + a_rd[kk] + i * 16 * kRowBytes);
+#pragma unroll
+            for (int j = 0; j < NF1; ++j) bfr[j] = *(const vec8*)(sbase + b1_rd[kk] + j * 16 * kRowBytes);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF1; ++j) acc1[i][j] = E::mfma(bfr[j], af[i], acc1[i][j]);
+        }
+    }
+
+    // ---- hand-over: everyone is done with the ring; W2 tile 0 starts streaming in while the
+    // intermediate tile is written (bias, ReLU, rounded to the storage type) in A-operand layout
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int w2_voff[W2_IT];
+#pragma unroll
+    for (int i = 0; i < W2_IT; ++i) w2_voff[i] = ((wave * W2_IT + i) * 8 + srow) * CMID * 2 + gchunk * 16;
+    auto stage_w2 = [&](int t) {
+        // rows t*128 .. t*128+127 of the packed 1x1 weights, KC chunks of 128 bytes each
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int i = 0; i < W2_IT; ++i)
+                glds16(w2_rsrc, w2_voff[i], t * 128 * CMID * 2 + kc * kRowBytes,
+                       smem + T_BYTES + kc * 128 * kRowBytes + (wave * W2_IT + i) * 8 * kRowBytes);
+    };
+    stage_w2(0);
+    {
+        constexpr int COLS1 = CMID / WN;
+#pragma unroll
+        for (int jj = 0; jj < NF1 / 2; ++jj) {
+            const int n = wn * COLS1 + jj * 32 + fq * 8;              // 8 consecutive intermediate channels
+            float bias_v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias_v[e] = d1.bias ? d1.bias[n + e] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int r = wm * (BM / WM) + i * 16 + frow;
+                vec8 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float lo = acc1[i][2 * jj][e] + bias_v[e], hi = acc1[i][2 * jj + 1][e] + bias_v[4 + e];
+                    if (d1.relu) { lo = fmaxf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }
+                    ov[e] = (scalar)lo;
+                    ov[4 + e] = (scalar)hi;
+                }
+                const int chunk = (n & 63) >> 3;
+                *(vec8*)(smem + (n >> 6) * A_BYTES + r * kRowBytes + ((chunk ^ (r & 7)) << 4)) = ov;
+            }
+        }
+    }
+
+    // ---- phase 2: y tile = T (BM x CMID) * W2^T, 128 output channels at a time
+    RowAddr ra[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+        ra[i] = row_addr(d2, m < Mg ? m : 0, HW, W, H, G2.H_res, G2.W_res, G2.out_off, G2.out_bstride, G2.res_off, G2.res_bstride);
+    }
+    const scalar* res = (const scalar*)d2.residual;
+    const int n2_tiles = d2.C_out / 128;
+    for (int t = 0; t < n2_tiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // W2 tile t (and, for t = 0, T) is in LDS
+        asm volatile("" ::: "memory");
+        f32x4 acc2[MF][NF2];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                vec8 af[MF], bfr[NF2];
+#pragma unroll
+                for (int i = 0; i < MF; ++i) af[i] = *(const vec8*)(smem + kc * A_BYTES + a_rd[kk] + i * 16 * kRowBytes);
+#pragma unroll
+                for (int j = 0; j < NF2; ++j) bfr[j] = *(const vec8*)(smem + kc * 128 * kRowBytes + b2_rd[kk] + j * 16 * kRowBytes);
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF2; ++j) acc2[i][j] = E::mfma(bfr[j], af[i], acc2[i][j]);
+            }
+        if (t + 1 < n2_tiles) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // everyone has read W2 tile t
+            asm volatile("" ::: "memory");
+            stage_w2(t + 1);                                           // streams in under the epilogue below
+        }
+#pragma unroll
+        for (int jj = 0; jj < NF2 / 2; ++jj) {
+            const int n = t * 128 + wn * 64 + jj * 32 + fq * 8;
+            float bias_v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias_v[e] = d2.bias ? d2.bias[n + e] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+                if (m >= Mg) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc2[i][2 * jj][e] + bias_v[e];
+                    v[4 + e] = acc2[i][2 * jj + 1][e] + bias_v[4 + e];
+                }
+                finish8<DT>(d2, v, n, ra[i].obase, res ? res + ra[i].rbase : nullptr);
+            }
+        }
+    }
+}
+
 // One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.
 template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
 int launch(gpp_conv_desc& d, hipStream_t st)
@@ -620,7 +848,65 @@ int validate(const gpp_conv_desc& d)
     return GPP_OK;
 }
 
+template <int DT, int BM, int CMID>
+int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, hipStream_t st)
+{
+    constexpr int lds = 2 * (BM + CMID) * kRowBytes;
+    static bool configured = false;
+    auto kernel = bottleneck_tail_kernel<DT, BM, CMID>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const gpp_conv_group& G = d1.groups[0];
+    const int64_t in_elems = G.in_off + (int64_t)(d1.batch - 1) * G.in_bstride + ((int64_t)G.H_in * G.W_in - 1) * d1.in_pitch + d1.C_in;
+    const int64_t w1_bytes = (int64_t)d1.weight_rows * 9 * CMID * 2, w2_bytes = (int64_t)d2.weight_rows * CMID * 2;
+    if (G.in_off < 0 || G.in_bstride < 0 || in_elems * 2 >= (1LL << 31) || w1_bytes >= (1LL << 31) || w2_bytes >= (1LL << 31))
+        return GPP_ERR_UNSUPPORTED;
+    d1.in_bytes = (int32_t)(in_elems * 2);
+    d1.weight_bytes = (int32_t)w1_bytes;
+    d2.weight_bytes = (int32_t)w2_bytes;
+    const int64_t rows = (int64_t)d1.batch * G.H_out * G.W_out;
+    kernel<<<dim3((unsigned)((rows + BM - 1) / BM)), dim3(256), lds, st>>>(d1, d2);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}
+
+template <int DT>
+int dispatch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st)
+{
+    const bool c64 = d1.C_in == 64;
+    switch (tile_rows) {
+        case 96: return c64 ? launch_tail<DT, 96, 64>(d1, d2, st) : launch_tail<DT, 96, 128>(d1, d2, st);
+        case 0:
+        case 128: return c64 ? launch_tail<DT, 128, 64>(d1, d2, st) : launch_tail<DT, 128, 128>(d1, d2, st);
+        case 160: return c64 ? launch_tail<DT, 160, 64>(d1, d2, st) : launch_tail<DT, 160, 128>(d1, d2, st);
+        default: return GPP_ERR_BAD_ARG;
+    }
+}
+
 }  // namespace
+
+extern "C" int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream)
+{
+    if (!conv3x3 || !conv1x1) return GPP_ERR_BAD_ARG;
+    gpp_conv_desc d1 = *conv3x3, d2 = *conv1x1;
+    int rc = validate(d1);
+    if (rc == GPP_OK) rc = validate(d2);
+    if (rc != GPP_OK) return rc;
+    const gpp_conv_group &G1 = d1.groups[0], &G2 = d2.groups[0];
+    // the pair this kernel fuses: 3x3 / stride 1 / pad 1 / C -> C (C = 64 or 128) feeding 1x1 / stride 1 / C -> multiple of 128
+    if (d1.dtype != d2.dtype || d1.n_groups != 1 || d2.n_groups != 1 || d1.batch != d2.batch) return GPP_ERR_UNSUPPORTED;
+    if (d1.KH != 3 || d1.KW != 3 || d1.stride != 1 || d1.pad_top != 1 || d1.pad_left != 1 || d1.residual || d1.out_f32) return GPP_ERR_UNSUPPORTED;
+    if (d1.C_in != d1.C_out || (d1.C_in != 64 && d1.C_in != 128) || d1.weight_rows < d1.C_out) return GPP_ERR_UNSUPPORTED;
+    if (d2.KH != 1 || d2.KW != 1 || d2.stride != 1 || d2.pad_top != 0 || d2.pad_left != 0 || d2.C_in != d1.C_out) return GPP_ERR_UNSUPPORTED;
+    if (d2.C_out % 128 != 0 || d2.weight_rows < d2.C_out) return GPP_ERR_UNSUPPORTED;
+    if (G1.H_in != G1.H_out || G1.W_in != G1.W_out || G2.H_out != G1.H_out || G2.W_out != G1.W_out || G2.H_in != G1.H_out || G2.W_in != G1.W_out)
+        return GPP_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    return d1.dtype == GPP_BF16 ? dispatch_tail<GPP_BF16>(d1, d2, tile_rows, st) : dispatch_tail<GPP_F16>(d1, d2, tile_rows, st);
+}
 
 extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)
 {

@@ -72,7 +72,11 @@ class PlanOp(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int32), ('tag', ctypes.c_int32), ('desc', ctypes.c_void_p)]
 
 
-OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL = 1, 2, 3, 4, 5, 6
+class TailDesc(ctypes.Structure):
+    _fields_ = [('conv3x3', ctypes.c_void_p), ('conv1x1', ctypes.c_void_p), ('tile_rows', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4, 5, 6, 7
 
 
 class Plan(object):
@@ -160,15 +164,29 @@ class RetinaNet3D(object):
             self._anchors[hw] = self.torch.as_tensor(anchor_utils.anchors_for_image(hw)).to(self.device).contiguous()
         return self._anchors[hw]
 
-    def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0):
+    def _desc(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False):
         wt, bias, shape = self.conv_w[name]
         kh, kw, cin, cout = shape
         if pad is None:
             pad = (0, 0)
-        d = C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
-                        residuals=residuals, dtype=self.dtype, out_f32=out_f32, workspace=plan.workspace)
+        return C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
+                           residuals=residuals, dtype=self.dtype, out_f32=out_f32, workspace=plan.workspace)
+
+    def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0):
+        d = self._desc(plan, name, inputs, outputs, K, stride, pad, relu, residuals, out_f32)
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d))
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
+
+    def _tail(self, plan, nm, a, y, shortcut):
+        """ branch2b (3x3) + branch2c (1x1, + shortcut, ReLU) of one bottleneck as ONE launch
+        (gpp_bottleneck_tail): the intermediate map never reaches HBM.  Bit-identical to the two layers. """
+        d1 = self._desc(plan, 'res{}_branch2b'.format(nm), [a], [a], 3, pad=(1, 1), relu=True)       # its `out` is never written
+        d2 = self._desc(plan, 'res{}_branch2c'.format(nm), [a], [y], 1, relu=True, residuals=[shortcut])
+        plan.keep += [d1, d2]
+        t = TailDesc(ctypes.addressof(d1), ctypes.addressof(d2), 0, 0)
+        name = 'res{}_branch2b+2c'.format(nm)
+        plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2))
+        plan.io[name] = ([a], [y], [shortcut])
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
         torch, dev, dt = self.torch, self.device, self.tdtype
@@ -204,6 +222,10 @@ class RetinaNet3D(object):
         # working set inside the 256 MiB Infinity Cache; measured on MI355X at B = 8 this LOSES 1-6 % (the smaller
         # launches cost more than the on-die re-reads save), so the default is the whole batch per launch.
         env_chunks = os.environ.get('GPP_STAGE_CHUNKS')
+        # widths whose branch2b + branch2c run as one launch (GPP_FUSE_TAIL=0 for none).  Measured at B = 8, same box,
+        # whole step: none 1553, res3 only 1562, res2 + res3 1571 images/s (in isolation the fused res2 launch is no
+        # faster than its two layers -- 122 us vs 36 + 80 -- but the step is: 69 MB less through HBM per block)
+        fuse_tail = [int(v) for v in os.environ.get('GPP_FUSE_TAIL', '64,128').split(',') if v.strip() and int(v) > 0]
 
         def sub(fm, c0, nb):
             return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch)
@@ -217,7 +239,8 @@ class RetinaNet3D(object):
                 nm = W.block_name(self.backbone_name, stage, block)
                 stride = 2 if (block == 0 and stage > 0) else 1
                 ho, wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
-                rec = {'nm': nm, 'stride': stride, 'a': fmap(ho, wo, f), 'b': fmap(ho, wo, f),
+                fused = f in fuse_tail and f in (64, 128)
+                rec = {'nm': nm, 'stride': stride, 'a': fmap(ho, wo, f), 'b': None if fused else fmap(ho, wo, f),
                        'sc': fmap(ho, wo, 4 * f) if block == 0 else None, 'y': fmap(ho, wo, 4 * f)}
                 blocks.append(rec)
                 x = rec['y']
@@ -227,15 +250,19 @@ class RetinaNet3D(object):
                 xs = sub(xin, c0, nb)
                 for rec in blocks:
                     nm, stride = rec['nm'], rec['stride']
-                    a_, b_, y_ = sub(rec['a'], c0, nb), sub(rec['b'], c0, nb), sub(rec['y'], c0, nb)
+                    a_, y_ = sub(rec['a'], c0, nb), sub(rec['y'], c0, nb)
                     self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True)
-                    self._conv(plan, 'res{}_branch2b'.format(nm), [a_], [b_], 3, pad=(1, 1), relu=True)
                     if rec['sc'] is not None:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride)
                     else:
                         sc_ = xs
-                    self._conv(plan, 'res{}_branch2c'.format(nm), [b_], [y_], 1, relu=True, residuals=[sc_])
+                    if rec['b'] is None:
+                        self._tail(plan, nm, a_, y_, sc_)
+                    else:
+                        b_ = sub(rec['b'], c0, nb)
+                        self._conv(plan, 'res{}_branch2b'.format(nm), [a_], [b_], 3, pad=(1, 1), relu=True)
+                        self._conv(plan, 'res{}_branch2c'.format(nm), [b_], [y_], 1, relu=True, residuals=[sc_])
                     xs = y_
             feats.append(x)
         _, C3, C4, C5 = feats
@@ -384,6 +411,26 @@ class RetinaNet3D(object):
             if kind in (OP_DETECT, OP_POLL):
                 continue
             self.run_op(plan, index)
+            if kind == OP_TAIL:
+                key = (name, B, H, Wd)
+                if key not in self._tuned:
+                    times = {}
+                    for rows in (96, 128, 160):
+                        desc.tile_rows = rows
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        self.run_op(plan, index)
+                        e0.record()
+                        for _ in range(16):
+                            self.run_op(plan, index)
+                        e1.record()
+                        e1.synchronize()
+                        times[rows] = e0.elapsed_time(e1) * 1000.0 / 16
+                    rows = min(times, key=times.get)
+                    self._tuned[key] = (rows, 1, round(times[rows], 2))
+                    fresh = True
+                desc.tile_rows = self._tuned[key][0]
+                plan.tuning[name] = self._tuned[key]
+                continue
             if kind != OP_CONV:
                 continue
             key = (name, B, H, Wd)

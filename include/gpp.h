@@ -150,6 +150,13 @@ int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream);
    Synchronises the stream.  Results do not depend on the tile choice; they depend on split_k only in the last bits. */
 int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* best_us);
 
+/* Fused tail of a ResNet bottleneck (keras_resnet bottleneck_2d, used at /root/reference/keras_retinanet_3D/models/
+   resnet.py:88-93): the 3x3 conv "branch2b" (C -> C, C = 64 or 128, stride 1, pad 1, + bias + ReLU) and the 1x1 conv
+   "branch2c" (C -> multiple of 128, + bias + residual + ReLU) in ONE launch; the intermediate map stays in LDS.
+   conv3x3->out is not written.  Results are bit-identical to gpp_conv2d_igemm(conv3x3) + gpp_conv2d_igemm(conv1x1).
+   tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup.  Other shapes: GPP_ERR_UNSUPPORTED. */
+int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream);
+
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
 
@@ -233,6 +240,7 @@ int gpp_detect_f32(const float* cls_logits, const float* regression, const float
 #define GPP_OP_RELU 4
 #define GPP_OP_DETECT 5
 #define GPP_OP_POLL 6
+#define GPP_OP_BOTTLENECK_TAIL 7
 
 typedef struct gpp_stem_desc { const float* in; const void* weight; const float* bias; void* out;
                                int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem) */
@@ -254,6 +262,8 @@ typedef struct gpp_poll_desc {
     int32_t B, D, N, planes_batched;
     float thr; int32_t reserved;
 } gpp_poll_desc;
+
+typedef struct gpp_tail_desc { const gpp_conv_desc* conv3x3; const gpp_conv_desc* conv1x1; int32_t tile_rows, reserved; } gpp_tail_desc;
 
 typedef struct gpp_plan_op { int32_t kind; int32_t tag; const void* desc; } gpp_plan_op;
 

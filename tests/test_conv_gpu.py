@@ -244,3 +244,52 @@ def test_autotune_picks_a_valid_configuration(case):
     got = out.buf.float().cpu()
     assert bool(((got - ref).abs() <= eps * ref.abs() + 1e-3).all())
     assert hip.lib().gpp_conv2d_autotune(None, 3, hip.stream_ptr(), None) == -1
+
+
+@pytest.mark.parametrize('tile_rows', [0, 96, 128, 160])
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('cmid,B,H,W,shortcut', [(64, 2, 25, 31, 'same'), (128, 1, 26, 21, 'same'), (64, 1, 7, 5, None), (128, 3, 9, 40, 'same')])
+def test_bottleneck_tail_equals_the_two_layers(cmid, B, H, W, shortcut, dtype, tile_rows):
+    """ gpp_bottleneck_tail (3x3 + 1x1 + residual in one launch, intermediate in LDS) must reproduce
+    the two separate launches bit for bit, and the unfused pair is checked against torch here too. """
+    g = torch.Generator().manual_seed(cmid + H)
+    tdt = C.torch_dtype(dtype)
+    dev = torch.device('cuda')
+    cout = 4 * cmid
+    a = torch.randn((B, H, W, cmid), generator=g).to(tdt)
+    k1 = (torch.randn((3, 3, cmid, cmid), generator=g) * (2.0 / (9 * cmid)) ** 0.5).to(tdt)
+    k2 = (torch.randn((1, 1, cmid, cout), generator=g) * (2.0 / cmid) ** 0.5).to(tdt)
+    b1, b2 = torch.randn((cmid,), generator=g) * 0.1, torch.randn((cout,), generator=g) * 0.1
+    sc = torch.randn((B, H, W, cout), generator=g).to(tdt) if shortcut else None
+    amap = C.FMap(a.to(dev).contiguous(), B, H, W, cmid)
+    mid = C.FMap.empty(B, H, W, cmid, tdt, dev)
+    y_sep, y_fused = C.FMap.empty(B, H, W, cout, tdt, dev), C.FMap.empty(B, H, W, cout, tdt, dev)
+    w1, w2 = C.pack_weight(k1.float().numpy(), dtype, dev), C.pack_weight(k2.float().numpy(), dtype, dev)
+    rmap = [C.FMap(sc.to(dev).contiguous(), B, H, W, cout)] if shortcut else None
+    b1d, b2d = b1.to(dev), b2.to(dev)                         # descriptors hold raw pointers: keep the tensors alive
+    d1 = C.conv_desc([amap], [mid], w1, b1d, 3, 3, cmid, cmid, pad=(1, 1), relu=True, dtype=dtype)
+    d2 = C.conv_desc([mid], [y_sep], w2, b2d, 1, 1, cmid, cout, relu=True, residuals=rmap, dtype=dtype)
+    C.run_conv(d1)
+    C.run_conv(d2)
+    want = y_sep.buf.float().cpu()
+    mid_ref = reference(a.float(), k1.float(), b1, 1, 1, 1, H, W, True, None).to(tdt).float()
+    ref = reference(mid_ref, k2.float(), b2, 1, 0, 0, H, W, True, None if sc is None else sc.float())
+    eps = 2.0 ** -7 if dtype == 'bf16' else 2.0 ** -9       # two roundings: the intermediate may differ by one step
+    assert ((want - ref).abs() <= eps * ref.abs() + 2e-2).float().mean() > 0.999
+    d2f = C.conv_desc([mid], [y_fused], w2, b2d, 1, 1, cmid, cout, relu=True, residuals=rmap, dtype=dtype)
+    mid.buf.fill_(float('nan'))                               # the fused launch must not depend on (or write) it
+    y_fused.buf.fill_(float('nan'))
+    hip.check(hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2f), tile_rows, hip.stream_ptr()), 'gpp_bottleneck_tail')
+    got = y_fused.buf.float().cpu()
+    assert torch.equal(got, want)
+    assert torch.isnan(mid.buf.float()).all()
+
+
+def test_bottleneck_tail_rejects_other_shapes():
+    make, _, _, _ = _layer('3x3')                             # 64 -> 64 3x3, fine as first half
+    make2, _, _, _ = _layer('1x1_s2')                         # strided 1x1 with 128 input channels
+    rc = hip.lib().gpp_bottleneck_tail(ctypes.byref(make(0)), ctypes.byref(make2(0)), 0, hip.stream_ptr())
+    assert rc == -4
+    assert hip.lib().gpp_bottleneck_tail(None, None, 0, hip.stream_ptr()) == -1
+    rc = hip.lib().gpp_bottleneck_tail(ctypes.byref(make(0)), ctypes.byref(make(0)), 0, hip.stream_ptr())   # 3x3 as second half
+    assert rc == -4

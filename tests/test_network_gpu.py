@@ -199,7 +199,7 @@ def test_every_layer_on_oracle_inputs(backbone, dtype):
     one rounding step.  Tolerance: |gpu - oracle| <= ulp |oracle| + 1e-4 * rms (ulp 2^-7 bf16, 2^-10 f16) and
     >= 99 % of elements bit-equal; float32 head outputs: <= 2e-5 * rms + 1e-5 |oracle|. """
     import torch
-    from keras_retinanet_3D.models.retinanet import OP_CONV, OP_MAXPOOL, OP_RELU, OP_STEM
+    from keras_retinanet_3D.models.retinanet import OP_CONV, OP_MAXPOOL, OP_RELU, OP_STEM, OP_TAIL
     batch, h, w = 2, 120, 200
     model50 = models.load_model('synthetic:1234', backbone_name=backbone, dtype=dtype)
     weights = W.synthetic_weights(backbone, 1234)
@@ -217,7 +217,7 @@ def test_every_layer_on_oracle_inputs(backbone, dtype):
                                    tr[('pyramid_regression_dim_0', level)]], axis=-1)
         if name == 'pyramid_regression_ops':
             return np.concatenate([tr[('pyramid_regression_op{}'.format(k), level)] for k in (1, 2, 3, 4, 5)], axis=-1)
-        return tr[(name, level)]
+        return tr[(name.replace('branch2b+2c', 'branch2c'), level)]      # fused 3x3 + 1x1 launch: output of the 1x1
 
     produced = {}                       # (buffer address, element offset) -> oracle array (B, H, W, C_total)
 
@@ -235,7 +235,7 @@ def test_every_layer_on_oracle_inputs(backbone, dtype):
         assert arr.shape == (fm.B, fm.H, fm.W, fm.C), (arr.shape, (fm.B, fm.H, fm.W, fm.C))
         fm.dense().copy_(torch.as_tensor(np.ascontiguousarray(arr)).to(fm.buf.dtype))
 
-    def compare(name, fm, want):
+    def compare(name, fm, want, slack=1e-4):
         got = fm.dense().float().cpu().numpy()
         assert got.shape == want.shape, (name, got.shape, want.shape)
         rms = float(np.sqrt((want.astype(np.float64) ** 2).mean())) + 1e-30
@@ -243,7 +243,7 @@ def test_every_layer_on_oracle_inputs(backbone, dtype):
         if fm.buf.dtype == torch.float32:
             assert (err <= 2e-5 * rms + 1e-5 * np.abs(want)).all(), (name, err.max(), rms)
         else:
-            assert (err <= np.abs(want) * ulp + 1e-4 * rms).all(), (name, err.max(), rms)
+            assert (err <= np.abs(want) * ulp + slack * rms).all(), (name, err.max(), rms)
             assert (got == want).mean() >= 0.99, (name, (got == want).mean())
 
     checked = 0
@@ -264,7 +264,7 @@ def test_every_layer_on_oracle_inputs(backbone, dtype):
             model50.run_op(plan, index)
             assert (dst.dense().float().cpu().numpy() == tr[('C6_relu', 0)]).all()
             register(dst, tr[('C6_relu', 0)])
-        elif kind == OP_CONV:
+        elif kind in (OP_CONV, OP_TAIL):
             inputs, outputs, residuals = plan.io[name]
             for fm in inputs + (residuals or []):
                 feed(fm)
@@ -272,7 +272,9 @@ def test_every_layer_on_oracle_inputs(backbone, dtype):
             torch.cuda.synchronize()
             for level, fm in enumerate(outputs):
                 want = oracle_of(name, level if len(outputs) > 1 else 0)
-                compare(name, fm, want)
+                # a fused 3x3 + 1x1 launch rounds its intermediate on the GPU: a rare one-step flip there moves
+                # all output channels of that pixel by ~|w| * 2^-8
+                compare(name, fm, want, slack=4e-3 if kind == OP_TAIL else 1e-4)
                 register(fm, want)
         else:
             continue
