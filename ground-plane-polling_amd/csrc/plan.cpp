@@ -5,14 +5,70 @@
 
 #include "gpp.h"
 
+namespace {
+
+// Side lanes: ops whose kind carries a lane number (kind | GPP_OP_LANE(lane), lane 1..kLanes) run on a
+// library-owned stream that forks from the caller's stream where the lane is first used; a lane-0 op
+// marked GPP_OP_JOIN (and the end of the plan) waits for all open lanes.  Independent chains of the graph (the three head
+// towers) overlap their ramp-up / tail phases this way; results do not change.
+constexpr int kLanes = 2;
+struct Lanes {
+    hipStream_t stream[kLanes] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, done[kLanes] = {nullptr, nullptr};
+    bool ready = false;
+    int init()
+    {
+        if (ready) return GPP_OK;
+        for (int l = 0; l < kLanes; ++l) {
+            hipError_t e = hipStreamCreateWithFlags(&stream[l], hipStreamNonBlocking);
+            if (e != hipSuccess) return (int)e;
+            e = hipEventCreateWithFlags(&done[l], hipEventDisableTiming);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+        if (e != hipSuccess) return (int)e;
+        ready = true;
+        return GPP_OK;
+    }
+};
+Lanes g_lanes;
+
+}  // namespace
+
 extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, void* const* events, int n_events)
 {
     if (!ops || n_ops < 0) return GPP_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t main_st = (hipStream_t)stream;
     int ev = 0;
+    bool active[kLanes] = {false, false};
     for (int i = 0; i < n_ops; ++i) {
-        const gpp_plan_op& op = ops[i];
+        gpp_plan_op op = ops[i];
         if (!op.desc) return GPP_ERR_BAD_ARG;
+        const int lane = (op.kind >> 8) & 0xff;
+        const bool join = (op.kind & GPP_OP_JOIN) != 0;
+        op.kind &= 0xff;
+        if (lane > kLanes) return GPP_ERR_BAD_ARG;
+        hipStream_t st = main_st;
+        if (lane > 0) {
+            int rc = g_lanes.init();
+            if (rc != GPP_OK) return rc;
+            st = g_lanes.stream[lane - 1];
+            if (!active[lane - 1]) {                    // fork: the lane starts after everything enqueued on the main stream so far
+                hipError_t e = hipEventRecord(g_lanes.fork, main_st);
+                if (e == hipSuccess) e = hipStreamWaitEvent(st, g_lanes.fork, 0);
+                if (e != hipSuccess) return (int)e;
+                active[lane - 1] = true;
+            }
+        } else if (join) {
+            for (int m = 0; m < kLanes; ++m) {          // this op consumes what the side lanes produced
+                if (!active[m]) continue;
+                hipError_t e = hipEventRecord(g_lanes.done[m], g_lanes.stream[m]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(main_st, g_lanes.done[m], 0);
+                if (e != hipSuccess) return (int)e;
+                active[m] = false;
+            }
+        }
+        void* stream = (void*)st;
         const bool timed = op.tag != 0 && events && ev + 1 < n_events;
         if (timed) {
             hipError_t e = hipEventRecord((hipEvent_t)events[ev], st);
@@ -66,6 +122,12 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
             if (e != hipSuccess) return (int)e;
             ev += 2;
         }
+    }
+    for (int m = 0; m < kLanes; ++m) {                  // a plan may not end inside a side lane
+        if (!active[m]) continue;
+        hipError_t e = hipEventRecord(g_lanes.done[m], g_lanes.stream[m]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main_st, g_lanes.done[m], 0);
+        if (e != hipSuccess) return (int)e;
     }
     return GPP_OK;
 }

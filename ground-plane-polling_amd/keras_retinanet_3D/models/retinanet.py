@@ -77,6 +77,7 @@ class TailDesc(ctypes.Structure):
 
 
 OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4, 5, 6, 7
+OP_JOIN = 0x10000
 
 
 class Plan(object):
@@ -86,18 +87,20 @@ class Plan(object):
         self.keep = []          # ctypes descriptors and torch buffers kept alive
         self.io = {}            # conv op name -> (input FMaps, output FMaps, residual FMaps or None)
         self.ops = []           # (kind, tag, desc, name, flops)
+        self.lanes = []         # per op: side-stream lane << 8 | join flag (include/gpp.h GPP_OP_LANE / GPP_OP_JOIN)
         self.array = None
         self.flops = 0.0
 
-    def add(self, kind, desc, name, tag=0, flops=0.0):
+    def add(self, kind, desc, name, tag=0, flops=0.0, lane=0, join=False):
         self.keep.append(desc)
         self.ops.append((kind, tag, desc, name, flops))
+        self.lanes.append((int(lane) << 8) | (OP_JOIN if join else 0))
         self.flops += flops
 
     def finalize(self):
         arr = (PlanOp * len(self.ops))()
         for i, (kind, tag, desc, _, _) in enumerate(self.ops):
-            arr[i].kind, arr[i].tag, arr[i].desc = kind, tag, ctypes.addressof(desc)
+            arr[i].kind, arr[i].tag, arr[i].desc = kind | self.lanes[i], tag, ctypes.addressof(desc)
         self.array = arr
 
 
@@ -164,17 +167,17 @@ class RetinaNet3D(object):
             self._anchors[hw] = self.torch.as_tensor(anchor_utils.anchors_for_image(hw)).to(self.device).contiguous()
         return self._anchors[hw]
 
-    def _desc(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False):
+    def _desc(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, lane=0):
         wt, bias, shape = self.conv_w[name]
         kh, kw, cin, cout = shape
         if pad is None:
             pad = (0, 0)
         return C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
-                           residuals=residuals, dtype=self.dtype, out_f32=out_f32, workspace=plan.workspace)
+                           residuals=residuals, dtype=self.dtype, out_f32=out_f32, workspace=plan.workspaces[lane])
 
-    def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0):
-        d = self._desc(plan, name, inputs, outputs, K, stride, pad, relu, residuals, out_f32)
-        plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d))
+    def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0, lane=0):
+        d = self._desc(plan, name, inputs, outputs, K, stride, pad, relu, residuals, out_f32, lane)
+        plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
     def _tail(self, plan, nm, a, y, shortcut):
@@ -193,7 +196,10 @@ class RetinaNet3D(object):
         plan = Plan()
         plan.shape = (B, H, Wd, n_planes, planes_batched)
         # split-K partial tiles of the under-filled deep-K layers (res5, P5..P7); reused by every launch
-        plan.workspace = torch.empty((64 << 20,), dtype=torch.uint8, device=dev)
+        # (one per stream lane: concurrent launches must not share partial tiles)
+        head_lanes = os.environ.get('GPP_HEAD_LANES', '0') != '0'
+        plan.workspaces = [torch.empty((64 << 20,), dtype=torch.uint8, device=dev) for _ in range(3 if head_lanes else 1)]
+        plan.workspace = plan.workspaces[0]
 
         def fmap(h, w, c, dtype=None):
             f = C.FMap.empty(B, h, w, c, dtype or dt, dev)
@@ -311,22 +317,26 @@ class RetinaNet3D(object):
         def slice_of(maps, c0, c):
             return [C.FMap(m.buf, B, m.H, m.W, c, off=m.off + c0, bstride=m.bstride, pitch=m.pitch) for m in maps]
 
-        def tower(prefix, width, src, tag=0):
+        def tower(prefix, width, src, tag=0, lane=0):
             for i in range(1, 4):
                 _, dst = pyramid(width)
-                self._conv(plan, '{}_{}'.format(prefix, i), src, dst, 3, pad=(1, 1), relu=True, tag=tag)
+                self._conv(plan, '{}_{}'.format(prefix, i), src, dst, 3, pad=(1, 1), relu=True, tag=tag, lane=lane)
                 src = dst
             return src
 
+        # the three towers are independent chains: optionally (GPP_HEAD_LANES=1) the two small ones run on side
+        # streams, forked after the fused first layer and joined by the decode, so that their launches fill the
+        # ramp-up / tail phases of the big regression-tower kernels
+        l_dim, l_cls = (1, 2) if head_lanes else (0, 0)
+        dim_t = tower('pyramid_regression_dim', 128, slice_of(wide_maps, 768, 128), lane=l_dim)
+        plan.regression_dim, dim_o = pyramid(36, torch.float32)
+        self._conv(plan, 'pyramid_regression_dim', dim_t, dim_o, 3, pad=(1, 1), out_f32=True, lane=l_dim)
+        cls_t = tower('pyramid_classification', 256, slice_of(wide_maps, 512, 256), lane=l_cls)
+        plan.cls_logits, cls_o = pyramid(96, torch.float32)
+        self._conv(plan, 'pyramid_classification', cls_t, cls_o, 3, pad=(1, 1), out_f32=True, lane=l_cls)
         reg_t = tower('pyramid_regression', 512, slice_of(wide_maps, 0, 512), tag=1)
         plan.regression, reg_o = pyramid(144, torch.float32)
         self._conv(plan, 'pyramid_regression_ops', reg_t, reg_o, 3, pad=(1, 1), out_f32=True)
-        dim_t = tower('pyramid_regression_dim', 128, slice_of(wide_maps, 768, 128))
-        plan.regression_dim, dim_o = pyramid(36, torch.float32)
-        self._conv(plan, 'pyramid_regression_dim', dim_t, dim_o, 3, pad=(1, 1), out_f32=True)
-        cls_t = tower('pyramid_classification', 256, slice_of(wide_maps, 512, 256))
-        plan.cls_logits, cls_o = pyramid(96, torch.float32)
-        self._conv(plan, 'pyramid_classification', cls_t, cls_o, 3, pad=(1, 1), out_f32=True)
 
         # ---- decode + NMS (RegressBoxes, RegressDims, FilterDetections)
         D = MAX_DETECTIONS
@@ -347,7 +357,7 @@ class RetinaNet3D(object):
                         plan.labels.data_ptr(), plan.orientations.data_ptr(), plan.anchor_index.data_ptr(),
                         plan.counts.data_ptr(), plan.detect_ws.data_ptr(), plan.detect_ws.numel(), plan.n_anchors,
                         B, anchor_utils.NUM_BASE_ANCHORS, 1, D, SCORE_THRESHOLD, NMS_THRESHOLD if self.nms else 2.0)
-        plan.add(OP_DETECT, dd, 'filtered_detections')
+        plan.add(OP_DETECT, dd, 'filtered_detections', join=True)
 
         # ---- ground-plane polling (FitRoadPlanes)
         plan.keypoints = torch.empty((B, D, 4, 3), dtype=f32, device=dev)

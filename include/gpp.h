@@ -241,6 +241,12 @@ int gpp_detect_f32(const float* cls_logits, const float* regression, const float
 #define GPP_OP_DETECT 5
 #define GPP_OP_POLL 6
 #define GPP_OP_BOTTLENECK_TAIL 7
+/* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
+   that forks from the caller's stream at the first op of that lane; `kind | GPP_OP_JOIN` on a lane-0 op makes it wait
+   for every open lane (the end of the plan joins too).  The caller orders the ops so that each lane only depends on
+   what was enqueued before its fork.  Used for the three independent head towers. */
+#define GPP_OP_LANE(l) ((l) << 8)
+#define GPP_OP_JOIN 0x10000
 
 typedef struct gpp_stem_desc { const float* in; const void* weight; const float* bias; void* out;
                                int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem) */

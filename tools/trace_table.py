@@ -9,19 +9,24 @@ sys.path.insert(0, os.path.join(ROOT, 'ground-plane-polling_amd'))
 from keras_retinanet_3D.models import weights as W  # noqa: E402
 
 
-def conv_names(backbone):
+def conv_names(backbone, fused_stages=(0, 1)):
+    """ launch order of models/retinanet.py:_build (fused 2b+2c launches are bottleneck_tail_kernel, not conv_igemm) """
     names = []
     for stage, n in enumerate(W.BLOCKS[backbone]):
         for b in range(n):
             nm = W.block_name(backbone, stage, b)
-            names += ['res%s_2a' % nm, 'res%s_2b' % nm] + (['res%s_br1' % nm] if b == 0 else []) + ['res%s_2c' % nm]
+            names += ['res%s_2a' % nm] + (['res%s_br1' % nm] if b == 0 else [])
+            names += ['res%s_2b+2c' % nm] if stage in fused_stages else ['res%s_2b' % nm, 'res%s_2c' % nm]
     names += ['C5_reduced', 'P5', 'C4_reduced', 'P4', 'C3_reduced', 'P3', 'P6', 'P7']
-    names += ['heads_0(fused)'] + ['reg_%d' % i for i in range(1, 4)] + ['reg_ops'] + ['dim_%d' % i for i in range(1, 4)] + ['dim_out']
-    names += ['cls_%d' % i for i in range(1, 4)] + ['cls_out']
+    names += ['heads_0(fused)'] + ['dim_%d' % i for i in range(1, 4)] + ['dim_out'] + ['cls_%d' % i for i in range(1, 4)] + ['cls_out']
+    names += ['reg_%d' % i for i in range(1, 4)] + ['reg_ops']
     return names
 
 
 def short(k):
+    m = re.search(r'bottleneck_tail_kernel<(\d+), (\d+), (\d+)>', k)
+    if m:
+        return 'fused tail %sx%s' % (m.group(2), m.group(3))
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>', k)
     if m:
         return 'igemm %sx%s w%sx%s s%s%s' % (m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), ' pipe' if m.group(7) in ('true', '1') else '')
@@ -35,9 +40,12 @@ def main(path, backbone='resnet50'):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     ours = [r for r in rows if 'at::native' not in r['Kernel_Name'] and 'rocclr' not in r['Kernel_Name']]
+    ours = [r for r in ours if 'preprocess' not in r['Kernel_Name']]
     starts = [i for i, r in enumerate(ours) if 'stem' in r['Kernel_Name']]
-    mid = int(len(starts) * 0.3)    # a step inside the timed region (bench.py ends with host-fed extra steps)
-    step = ours[starts[mid]:starts[mid + 1]] if len(starts) > mid + 1 else ours[starts[-1]:]
+    # complete steps = stem ... poll; bench.py's timed steps come first, the host-fed extra steps after them:
+    # take the middle of the first 13 (warmup 3 + 10 timed with the profiling command of profiles/README.md)
+    steps = [ours[a:b] for a, b in zip(starts, starts[1:] + [len(ours)]) if any('poll_kernel' in r['Kernel_Name'] for r in ours[a:b])]
+    step = steps[min(8, len(steps) - 1)]
     names = conv_names(backbone)
     ci = 0
     t0 = int(step[0]['Start_Timestamp'])
@@ -47,7 +55,7 @@ def main(path, backbone='resnet50'):
         k = r['Kernel_Name']
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         total += d
-        if 'conv_igemm' in k:
+        if 'conv_igemm' in k or 'bottleneck_tail' in k:
             name = names[ci] if ci < len(names) else '?'
             ci += 1
         elif 'splitk_reduce' in k:
