@@ -175,9 +175,10 @@ class RetinaNet3D(object):
         return C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
                            residuals=residuals, dtype=self.dtype, out_f32=out_f32, workspace=plan.workspaces[lane])
 
-    def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0, lane=0):
+    def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0, lane=0,
+              join=False):
         d = self._desc(plan, name, inputs, outputs, K, stride, pad, relu, residuals, out_f32, lane)
-        plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane)
+        plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
     def _tail(self, plan, nm, a, y, shortcut):
@@ -290,21 +291,24 @@ class RetinaNet3D(object):
 
         pyr, P = pyramid(512)
         T5 = fmap(C5.H, C5.W, 512)
+        # P5 and the P6 -> ReLU -> P7 chain are small launches (a few dozen tiles) independent of the C4 / C3 chain:
+        # with GPP_HEAD_LANES=1 they run on the side streams underneath the big P4 / P3 launches
+        l_p5, l_p6 = (1, 2) if head_lanes else (0, 0)
         self._conv(plan, 'C5_reduced', [C5], [T5], 1)
-        self._conv(plan, 'P5', [T5], [P[2]], 3, pad=(1, 1))
+        self._conv(plan, 'P5', [T5], [P[2]], 3, pad=(1, 1), lane=l_p5)
+        self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]), lane=l_p6)
+        R6 = fmap(shapes[3][0], shapes[3][1], 512)
+        plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * 2, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
+                                   pix[3] * 512, C.gpp_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
+        plan.relu_io = (P[3], R6)
+        self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
+                   pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]), lane=l_p6)
         T4 = fmap(C4.H, C4.W, 512)
         self._conv(plan, 'C4_reduced', [C4], [T4], 1, residuals=[T5])          # + UpsampleLike(P5, C4), fused
         self._conv(plan, 'P4', [T4], [P[1]], 3, pad=(1, 1))
         T3 = fmap(C3.H, C3.W, 512)
         self._conv(plan, 'C3_reduced', [C3], [T3], 1, residuals=[T4])          # + UpsampleLike(P4, C3), fused
         self._conv(plan, 'P3', [T3], [P[0]], 3, pad=(1, 1))
-        self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]))
-        R6 = fmap(shapes[3][0], shapes[3][1], 512)
-        plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * 2, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
-                                   pix[3] * 512, C.gpp_dtype(self.dtype), B), 'C6_relu')
-        plan.relu_io = (P[3], R6)
-        self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
-                   pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]))
 
         plan.features.update({'P{}'.format(i + 3): P[i] for i in range(5)})
 
@@ -312,7 +316,7 @@ class RetinaNet3D(object):
         # layer 0 of the three towers shares its input: one fused launch (C_out = 896) into a wide
         # tensor; layers 1..3 read their channel slice of it (in_pitch > C_in)
         wide, wide_maps = pyramid(896)
-        self._conv(plan, 'pyramid_towers_0', P, wide_maps, 3, pad=(1, 1), relu=True)
+        self._conv(plan, 'pyramid_towers_0', P, wide_maps, 3, pad=(1, 1), relu=True, join=True)
 
         def slice_of(maps, c0, c):
             return [C.FMap(m.buf, B, m.H, m.W, c, off=m.off + c0, bstride=m.bstride, pitch=m.pitch) for m in maps]

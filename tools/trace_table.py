@@ -17,7 +17,7 @@ def conv_names(backbone, fused_stages=(0, 1)):
             nm = W.block_name(backbone, stage, b)
             names += ['res%s_2a' % nm] + (['res%s_br1' % nm] if b == 0 else [])
             names += ['res%s_2b+2c' % nm] if stage in fused_stages else ['res%s_2b' % nm, 'res%s_2c' % nm]
-    names += ['C5_reduced', 'P5', 'C4_reduced', 'P4', 'C3_reduced', 'P3', 'P6', 'P7']
+    names += ['C5_reduced', 'P5', 'P6', 'P7', 'C4_reduced', 'P4', 'C3_reduced', 'P3']
     names += ['heads_0(fused)'] + ['dim_%d' % i for i in range(1, 4)] + ['dim_out'] + ['cls_%d' % i for i in range(1, 4)] + ['cls_out']
     names += ['reg_%d' % i for i in range(1, 4)] + ['reg_ops']
     return names
