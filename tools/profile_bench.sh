@@ -1,13 +1,27 @@
 #!/bin/bash
-# Kernel trace + stats of bench.py (1 GPU), then the per-launch table of one step.  Usage (on the GPU box):
-#   bash tools/profile_bench.sh [outdir under gpurun_out]
+# Kernel trace + stats of bench.py (1 GPU), then the per-launch table of one step and the dominant-kernel summary.
+# Usage (on the GPU box):  bash tools/profile_bench.sh [outdir under gpurun_out]
+# A first un-profiled run writes the per-layer tile choices to a cache, so that the profiled run contains no
+# autotuning launches and its --stats averages are those of the steady state.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=${1:-gpurun_out/prof}
 mkdir -p $out
+export GPP_TUNE_CACHE=$GRAFT_REPO_ROOT/$out/tune_cache.json
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/tuning_run.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
-grep "^{\"metric\"" $out/bench_under_rocprof.log > $out/bench_under_rocprof.json
+grep '^{"metric"' $out/bench_under_rocprof.log > $out/bench_under_rocprof.json
 trace=$(find $out/trace -name '*kernel_trace.csv' | head -1)
 stats=$(find $out/trace -name '*kernel_stats.csv' | head -1)
 cp "$stats" $out/kernel_stats.csv
 python3 tools/trace_table.py "$trace" > $out/per_layer.txt
-tail -4 $out/per_layer.txt
+tail -3 $out/per_layer.txt
+python3 - "$trace" > $out/dominant_kernel_trace_summary.txt <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1]))
+        if 'conv_igemm_kernel<1, 256, 256, 2, 4, 2, true>' in r['Kernel_Name'] and int(r['Grid_Size_X']) == 722 * 512]
+d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows]
+print('conv_igemm_kernel<bf16,256,256,2,4,2,pipe>, grid 722 workgroups x 512 threads = the regression-tower layers')
+print('(3x3, 512->512, five pyramid levels, M = 91504, 431.8 GFLOP per launch), from the rocprofv3 kernel trace:')
+print('launches %d  mean %.1f us  min %.1f us  max %.1f us  ->  %.1f TFLOP/s at the mean' % (len(d), sum(d) / len(d), min(d), max(d), 431.8e3 / (sum(d) / len(d))))
+PY
+cat $out/dominant_kernel_trace_summary.txt
