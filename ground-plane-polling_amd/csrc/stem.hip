@@ -111,26 +111,48 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias_v[jj][e] = bias[jj * 32 + fq * 8 + e];
 
-    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    // The input patch of a tile (MP_ROWS x MP_PITCH halfs) is fetched by all 256 threads, PATCH_IT pairs of
+    // floats each.  All loads of a tile are issued back to back into registers (one latency, not PATCH_IT of
+    // them), and they are issued for the NEXT tile before the MFMA work of the current one, so the fetch
+    // runs under the matrix work and the output stores.
+    constexpr int PATCH_PAIRS = MP_ROWS * (MP_PITCH / 2);
+    constexpr int PATCH_IT = (PATCH_PAIRS + 255) / 256;
+    float patch[PATCH_IT][2];          // raw floats: converting at load time would make the loads blocking
+    auto load_patch = [&](int t) {
         const int b = t / (tiles_x * tiles_y), r = t - b * (tiles_x * tiles_y);
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
-        const int ox0 = tx * TW, oy0 = ty * TH;
-        const int ix0 = ox0 * 2 - 3, iy0 = oy0 * 2 - 3;
+        const int ix0 = tx * TW * 2 - 3, iy0 = ty * TH * 2 - 3;
         const float* img = in + (size_t)b * H * W * 3;
-        __syncthreads();                                     // previous tile's readers are done with s_p
-        for (int e = tid; e < MP_ROWS * (MP_PITCH / 2); e += 256) {
+#pragma unroll
+        for (int it = 0; it < PATCH_IT; ++it) {
+            const int e = tid + it * 256;
             const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
             const int iy = iy0 + pr;
+            const int x0 = ix0 * 3 + c2;                     // element index inside the image row
             float v0 = 0.0f, v1 = 0.0f;
-            if ((unsigned)iy < (unsigned)H) {
-                const int x0 = ix0 * 3 + c2;                 // element index inside the image row
+            if (e < PATCH_PAIRS && (unsigned)iy < (unsigned)H) {
                 const float* rowp = img + (size_t)iy * W * 3;
                 if (x0 >= 0 && x0 < W * 3) v0 = rowp[x0];
                 if (x0 + 1 >= 0 && x0 + 1 < W * 3) v1 = rowp[x0 + 1];
             }
-            *(f16x2*)(s_p + pr * MP_PITCH + c2) = (f16x2){(_Float16)v0, (_Float16)v1};
+            patch[it][0] = v0;
+            patch[it][1] = v1;
+        }
+    };
+    if ((int)blockIdx.x < tiles) load_patch(blockIdx.x);
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int b = t / (tiles_x * tiles_y), r = t - b * (tiles_x * tiles_y);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int ox0 = tx * TW, oy0 = ty * TH;
+        __syncthreads();                                     // previous tile's readers are done with s_p
+#pragma unroll
+        for (int it = 0; it < PATCH_IT; ++it) {
+            const int e = tid + it * 256;
+            const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
+            if (e < PATCH_PAIRS) *(f16x2*)(s_p + pr * MP_PITCH + c2) = (f16x2){(_Float16)patch[it][0], (_Float16)patch[it][1]};
         }
         __syncthreads();
+        if (t + (int)gridDim.x < tiles) load_patch(t + gridDim.x);
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -276,7 +298,7 @@ extern "C" int gpp_stem_conv7x7_bn_relu_mfma(const float* in, const void* packed
     if (((uintptr_t)out | (uintptr_t)packed_weight_f16) & 15) return GPP_ERR_ALIGN;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     const int tiles = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * B;
-    const unsigned grid = (unsigned)(tiles < 768 ? tiles : 768);
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);      // 2 workgroups / CU (register-limited), persistent
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GPP_BF16)
         stem_mfma_kernel<__bf16, bf16x8><<<grid, 256, 0, st>>>(in, (const _Float16*)packed_weight_f16, bias, (__bf16*)out, B, H, W, Ho, Wo);

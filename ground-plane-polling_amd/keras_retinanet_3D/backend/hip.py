@@ -14,7 +14,8 @@ import os
 
 _LIB = None
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libgpp_hip.so'))
+# GPP_LIB: alternative build of the library (A/B timing of kernel changes); default = the in-tree build
+LIB_PATH = os.environ.get('GPP_LIB') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libgpp_hip.so'))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, '..', '..', 'csrc'))
 
 GPP_OK = 0
