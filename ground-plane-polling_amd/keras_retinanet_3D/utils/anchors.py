@@ -54,3 +54,17 @@ def anchors_for_image(image_hw):
         centre[..., 0, 3] = cy[:, None]
         chunks.append((centre + base[None, None]).reshape(-1, 4))
     return np.ascontiguousarray(np.concatenate(chunks, axis=0), dtype=np.float32)
+
+
+def compute_overlap(a, b):
+    """ IoU of every box of a (N, 4) with every box of b (K, 4) -> (N, K), float64; the union is
+    clamped to machine epsilon so degenerate boxes give 0, not NaN (utils/anchors.py:339-363). """
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    iw = np.clip(np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0]), 0, None)
+    ih = np.clip(np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1]), 0, None)
+    inter = iw * ih
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    union = np.maximum(area_a[:, None] + area_b[None, :] - inter, np.finfo(float).eps)
+    return inter / union

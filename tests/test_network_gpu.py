@@ -169,6 +169,51 @@ def test_run_network_cli_on_the_gpu(tmp_path):
         assert txt.count('\n') == n and txt.startswith('Car -1 -1 ')
 
 
+def test_evaluate_cli_on_the_gpu(tmp_path, model50):
+    """ utils.eval.evaluate through the real model on a KITTI-style directory: ground truth is taken from the model's own
+    detections of two frames (every second one, original pixel units), so the matching, AP and error code see real
+    GPU outputs; batched and one-at-a-time evaluation agree exactly """
+    import scipy.io
+    from PIL import Image
+    from keras_retinanet_3D.bin import evaluate as evaluate_cli
+    from keras_retinanet_3D.preprocessing.kitti import KittiGenerator
+    from keras_retinanet_3D.utils import eval as gpp_eval, image
+    base = tmp_path / 'kitti'
+    for d in ('images', 'labels', 'calibs'):
+        (base / 'val' / d).mkdir(parents=True)
+    planes = synthetic.load_plane_database('100')
+    scipy.io.savemat(str(base / 'road_planes_database.mat'), {'road_planes_database': planes})
+    P2 = synthetic.KITTI_LIKE_P2
+    calib = 'P0: ' + ' '.join(['0'] * 12) + '\nP1: ' + ' '.join(['0'] * 12) + '\nP2: ' + ' '.join('%.12e' % v for v in P2.reshape(-1)) + '\n'
+    total = 0
+    for k in range(3):
+        frame = (np.random.default_rng(k).integers(0, 2, size=(120, 200, 3)) * 255).astype(np.uint8)
+        Image.fromarray(frame[:, :, ::-1]).save(str(base / 'val' / 'images' / ('%06d.png' % k)))
+        (base / 'val' / 'calibs' / ('%06d.txt' % k)).write_text(calib)
+        img, scale = image.resize_image(image.preprocess_image(image.read_image_bgr(str(base / 'val' / 'images' / ('%06d.png' % k)))))
+        P_inv = np.linalg.pinv(np.diag([scale, scale, 1.0]).dot(P2))
+        out = model50.predict_on_batch([img[None], P_inv[None], planes[None]])
+        lines = []
+        for d in range(0, int((out[2][0] > 0.05).sum()), 2):
+            b = out[0][0, d] / scale
+            lines.append('Car 0.00 0 0.00 ' + ' '.join('%.4f' % v for v in b) + ' ' + ' '.join('%.4f' % v for v in out[1][0, d]) +
+                         ' %d' % out[4][0, d])
+        total += len(lines)
+        (base / 'val' / 'labels' / ('%06d.txt' % k)).write_text('\n'.join(lines) + ('\n' if lines else ''))
+    assert total > 0
+    gen = KittiGenerator(str(base), subset='val')
+    one = gpp_eval.evaluate(gen, model50, batch_size=1)
+    many = gpp_eval.evaluate(gen, model50, batch_size=3)
+    assert sorted(one[0]) == [0, 1, 2, 3] and sum(n for _, n in one[0].values()) == total
+    for label in one[0]:
+        assert one[0][label] == many[0][label]
+    assert one[1:] == many[1:]
+    assert max(ap for ap, n in one[0].values() if n > 0) > 0.3        # its own detections are found again
+    assert one[1] < 1e-3 and one[2] < 1e-3                            # matched keypoints / heights equal the labels (%.4f)
+    logs = evaluate_cli.main(['synthetic:1234.h5', str(base), '--batch-size', '2'])
+    assert 0.0 < logs['mAP'] <= 1.0
+
+
 def test_frame_pipeline_matches_synchronous_calls(model50):
     from keras_retinanet_3D.utils.pipeline import FramePipeline
     from keras_retinanet_3D.utils import image
