@@ -71,6 +71,19 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int voffset,
 
 constexpr int kOutOfRange = (int)0x80000000;
 
+// Diagnostic build only (-DGPP_STAMPS, tools/bench_conv.py stamps): wave 0 of every workgroup writes the 100 MHz
+// real-time counter at five points into a buffer of its own (handed in through the otherwise unused zero_page
+// field when reserved bit 4 is set).  No output depends on it; the production build contains none of this.
+#ifdef GPP_STAMPS
+#define GPP_STAMP(k)                                                                                          \
+    do {                                                                                                      \
+        if ((d.reserved & 16) && wave == 0 && lane == 0)                                                      \
+            ((unsigned long long*)d.zero_page)[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GPP_STAMP(k) do { } while (0)
+#endif
+
 // Bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous tile range.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 {
@@ -161,6 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    GPP_STAMP(0);
 
     // ---- which tile
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    GPP_STAMP(1);
     // ---- main loop.  Ring of STAGES buffers, PF = STAGES-1 K-steps of LDS-DMA in flight; one raw
     // s_barrier per K-step.  At the top of step ks a counted vmcnt retires this wave's loads of
     // stage ks only (later stages stay in flight across the barrier); after the barrier every
@@ -334,7 +349,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
             if (live) advance_tap();
         }
         load_frags(a0, b0, 0, 0);
+        // static priority for the later-dispatched half of an 8-wavefront workgroup: it loses every issue arbitration to
+        // its SIMD partner otherwise (measured +0.5 ... 2 % on the 256 x 256 tile; no effect on results)
+        if (NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
         for (int ks = 0; ks < nk; ++ks) {
+#ifdef GPP_STAMPS
+            if ((d.reserved & 32) && blockIdx.x < 64 && ks < 120 && wave == 0 && lane == 0)     // per-K-step timeline of a few workgroups
+                ((unsigned long long*)d.zero_page)[(1 << 19) + blockIdx.x * 128 + ks] = __builtin_amdgcn_s_memrealtime();
+#endif
             const int cur = ks & 1;
             const unsigned char* scur = smem + cur * STAGE;
             const unsigned char* snxt = smem + (cur ^ 1) * STAGE;
@@ -371,6 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
             }
             if (live) advance_tap();         // a_voff for the next issue changes only after this step's DMA is out
         }
+        if (NW == 8) __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll
     for (int p = 0; p < PF; ++p)
@@ -398,6 +421,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
         if (++cbuf == STAGES) cbuf = 0;
     }
     }
+    GPP_STAMP(2);
     // ---- epilogue, straight from registers.  The MFMA was issued as D = W_tile * X_tile^T, so
     // lane (fq = lane>>4, c = lane&15) of accumulator (i, j) holds output pixel i*16 + c and the four
     // weight-tile rows fq*4 + 0..3 of N-tile j.  The packed weight rows are interleaved on the host
@@ -449,6 +473,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
             finish8<DT>(d, v, n, ra.obase, rrow);
         }
     }
+    GPP_STAMP(3);
+#ifdef GPP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GPP_STAMP(4);
 }
 
 // Second pass of a split-K launch: sum the partial slabs in split order (deterministic), then the
@@ -802,6 +831,12 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
         case 1192128: return launch<DT, 192, 128, 2, 2, 2, true>(d, st);
         case 1128256: return launch<DT, 128, 256, 2, 4, 2, true>(d, st);
         case 1192256: return launch<DT, 192, 256, 2, 4, 2, true>(d, st);
+        // N-remainder tiles (4 x 1 wavefronts, wave tile BM/4 x 160): layers whose C_out is far from a multiple of 128
+        // (regression outputs: 144 -> 160 instead of 256 columns; measured 200 -> 162 us).  96-wide tiles and 3/4-deep
+        // LDS rings on the small tiles were measured too and lost everywhere (fewer workgroups per CU).
+        case 128160: return launch<DT, 128, 160, 4, 1, 2, false>(d, st);
+        case 192160: return launch<DT, 192, 160, 4, 1, 2, false>(d, st);
+        case 1192160: return launch<DT, 192, 160, 4, 1, 2, true>(d, st);
         case 512:
         case 256256: return (d.reserved & 8) ? launch<DT, 256, 256, 2, 4, 2, false>(d, st) : launch<DT, 256, 256, 2, 4, 2, true>(d, st);
         case 0: break;
@@ -937,7 +972,8 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
 {
     if (!desc || iters < 1) return GPP_ERR_BAD_ARG;
     static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
-                                 1128128, 1192128, 1128256, 1192256, 256256};
+                                 1128128, 1192128, 1128256, 1192256, 256256,
+                                 128160, 192160, 1192160};
     static const int kSplits[] = {1, 2, 3, 4, 6, 8};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
@@ -975,6 +1011,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
         if (bn == 256 && (desc->C_out < 192 || rows < 256 * 128)) continue;
         if (tile > 1000000 && nk < 4) continue;                      // the pipelined loop needs a few K-steps to pay
+        if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding
         float us = 0.0f;
         int r = time_one(tile, tile == 0 ? split_in : 1, &us);
         if (r != GPP_OK) { if (tile == 0) { rc = r; break; } continue; }

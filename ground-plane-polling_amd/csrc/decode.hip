@@ -26,6 +26,10 @@ namespace {
 
 constexpr int kCounterStride = 4096;              // bytes between the candidate counters of two images
 constexpr int kHeaderBytes = 64 * kCounterStride;  // up to 64 images per call
+// inside an image's header slot: word 0 = candidate counter, word 1 = number of NMS survivors, and from byte 1024 the
+// survivors' keys (<= 128 x 8 bytes), written by nms_kernel for emit_kernel
+constexpr int kKeptCountWord = 1;
+constexpr int kKeptKeysOffset = 1024;
 
 // ---- Cephes expf, one float32 operation at a time (mirrors oracle/decode_np.py:cephes_expf)
 __device__ __forceinline__ float cephes_expf(float x)
@@ -297,9 +301,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(
     unsigned long long* __restrict__ keys, const int32_t* __restrict__ counts, int64_t key_stride,
     const float* __restrict__ cls, const float* __restrict__ reg, const float* __restrict__ regdim,
     const float4* __restrict__ anchors, int64_t n_anchors, Layout L, float iou_thr, int max_det,
-    float* __restrict__ o_boxes, float* __restrict__ o_dims, float* __restrict__ o_scores,
-    int32_t* __restrict__ o_labels, int32_t* __restrict__ o_orient, int32_t* __restrict__ o_anchor,
-    int32_t* __restrict__ o_counts, float4* __restrict__ ws_boxes, unsigned char* __restrict__ ws_alive)
+    int32_t* __restrict__ o_counts, float4* __restrict__ ws_boxes, unsigned char* __restrict__ ws_alive,
+    unsigned char* __restrict__ header)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
     unsigned long long* lkeys = (unsigned long long*)nms_smem;                 // kLdsKeys keys while sorting ...
@@ -442,14 +445,34 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(
         }
     }
 
-    // ---- outputs: survivors in score order (tf.nn.top_k of an already sorted list is the identity),
-    //      then -1 padding (filter_detections.py:159-177)
-    for (int t = tid; t < max_det; t += kNmsThreads) {
+    // ---- hand-over to emit_kernel: the keys of the survivors, in score order, next to this image's counter
+    __syncthreads();
+    unsigned char* slot = header + (int64_t)b * kCounterStride;
+    if (tid == 0) ((int32_t*)slot)[kKeptCountWord] = kept;
+    for (int t = tid; t < kept; t += kNmsThreads) ((unsigned long long*)(slot + kKeptKeysOffset))[t] = sk[sh.kept[t]];
+}
+
+// Outputs of one image from the survivors' keys: full box / dimension decode, scores re-derived from the logits,
+// in score order (tf.nn.top_k of an already sorted list is the identity), then -1 padding
+// (filter_detections.py:155-177).  A separate launch so that the selection above only depends on the
+// classification logits and the four corner regressions: in a plan it runs on a side stream underneath the
+// dimension tower, and this kernel joins once every head tensor is there.
+__global__ __launch_bounds__(128) void emit_kernel(
+    const unsigned char* __restrict__ header, const float* __restrict__ cls, const float* __restrict__ reg,
+    const float* __restrict__ regdim, const float4* __restrict__ anchors, int64_t n_anchors, Layout L, int max_det,
+    float* __restrict__ o_boxes, float* __restrict__ o_dims, float* __restrict__ o_scores,
+    int32_t* __restrict__ o_labels, int32_t* __restrict__ o_orient, int32_t* __restrict__ o_anchor)
+{
+    const int b = blockIdx.x;
+    const unsigned char* slot = header + (int64_t)b * kCounterStride;
+    const int kept = ((const int32_t*)slot)[kKeptCountWord];
+    const unsigned long long* kk = (const unsigned long long*)(slot + kKeptKeysOffset);
+    for (int t = threadIdx.x; t < max_det; t += 128) {
         float* ob = o_boxes + ((int64_t)b * max_det + t) * 12;
         float* od = o_dims + ((int64_t)b * max_det + t) * 3;
         const int64_t row = (int64_t)b * max_det + t;
         if (t < kept) {
-            const unsigned long long key = sk[sh.kept[t]];
+            const unsigned long long key = kk[t];
             const int64_t a = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
             const float4* src = (const float4*)(cls + ((int64_t)b * n_anchors + a) * 8);
             const float4 v0 = src[0], v1 = src[1];
@@ -496,13 +519,14 @@ extern "C" int gpp_detect_workspace_bytes(int B, int64_t n_anchors, size_t* byte
     return GPP_OK;
 }
 
-extern "C" int gpp_detect_f32(const float* cls_logits, const float* regression, const float* regression_dim,
-                              const float* anchors, int B, int64_t n_anchors, int num_base_anchors, int fused_layout,
-                              float score_thr, float iou_thr, int max_det,
-                              float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
-                              int32_t* anchor_index, int32_t* counts,
-                              void* workspace, size_t workspace_bytes, void* stream)
+extern "C" int gpp_detect_stages_f32(int stages, const float* cls_logits, const float* regression,
+                                     const float* regression_dim, const float* anchors, int B, int64_t n_anchors,
+                                     int num_base_anchors, int fused_layout, float score_thr, float iou_thr, int max_det,
+                                     float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
+                                     int32_t* anchor_index, int32_t* counts,
+                                     void* workspace, size_t workspace_bytes, void* stream)
 {
+    if (stages <= 0 || stages > 7) return GPP_ERR_BAD_ARG;
     if (B < 0 || n_anchors <= 0 || max_det <= 0 || max_det > 128 || num_base_anchors <= 0) return GPP_ERR_BAD_ARG;
     if (n_anchors >= (1LL << 31) || n_anchors % num_base_anchors != 0) return GPP_ERR_UNSUPPORTED;
     if (B == 0) return GPP_OK;
@@ -523,20 +547,40 @@ extern "C" int gpp_detect_f32(const float* cls_logits, const float* regression, 
     unsigned long long* keys = (unsigned long long*)(ws + kHeaderBytes);
     float4* wboxes = (float4*)(ws + kHeaderBytes + (size_t)B * kstride * 8);
     unsigned char* alive = (unsigned char*)(wboxes + (size_t)B * n_anchors);
-    hipError_t e = hipMemsetAsync(cnt, 0, kHeaderBytes, st);
-    if (e != hipSuccess) return (int)e;
-    candidates_kernel<<<dim3((unsigned)((n_anchors + 255) / 256), (unsigned)B), 256, 0, st>>>(
-        cls_logits, n_anchors, kstride, score_thr, keys, cnt);
-    static bool configured = false;
-    if (!configured) {
-        e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsKeys * 16 + kHistBins * 4);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
     Layout L = {fused_layout, num_base_anchors};
-    nms_kernel<<<dim3((unsigned)B), kNmsThreads, kLdsKeys * 16 + kHistBins * 4, st>>>(
-        keys, cnt, kstride, cls_logits, regression, regression_dim, (const float4*)anchors, n_anchors, L, iou_thr, max_det,
-        boxes, dims, scores, labels, orientations, anchor_index, counts, wboxes, alive);
+    hipError_t e;
+    if (stages & GPP_DETECT_CANDIDATES) {                  // needs cls_logits only
+        e = hipMemsetAsync(cnt, 0, kHeaderBytes, st);
+        if (e != hipSuccess) return (int)e;
+        candidates_kernel<<<dim3((unsigned)((n_anchors + 255) / 256), (unsigned)B), 256, 0, st>>>(
+            cls_logits, n_anchors, kstride, score_thr, keys, cnt);
+    }
+    if (stages & GPP_DETECT_SELECT) {                      // needs the candidates and the corner regressions
+        static bool configured = false;
+        if (!configured) {
+            e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsKeys * 16 + kHistBins * 4);
+            if (e != hipSuccess) return (int)e;
+            configured = true;
+        }
+        nms_kernel<<<dim3((unsigned)B), kNmsThreads, kLdsKeys * 16 + kHistBins * 4, st>>>(
+            keys, cnt, kstride, cls_logits, regression, regression_dim, (const float4*)anchors, n_anchors, L, iou_thr, max_det,
+            counts, wboxes, alive, ws);
+    }
+    if (stages & GPP_DETECT_EMIT)                          // needs every head tensor
+        emit_kernel<<<dim3((unsigned)B), 128, 0, st>>>(ws, cls_logits, regression, regression_dim, (const float4*)anchors, n_anchors,
+                                                       L, max_det, boxes, dims, scores, labels, orientations, anchor_index);
     e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
+}
+
+extern "C" int gpp_detect_f32(const float* cls_logits, const float* regression, const float* regression_dim,
+                              const float* anchors, int B, int64_t n_anchors, int num_base_anchors, int fused_layout,
+                              float score_thr, float iou_thr, int max_det,
+                              float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
+                              int32_t* anchor_index, int32_t* counts,
+                              void* workspace, size_t workspace_bytes, void* stream)
+{
+    return gpp_detect_stages_f32(GPP_DETECT_CANDIDATES | GPP_DETECT_SELECT | GPP_DETECT_EMIT, cls_logits, regression, regression_dim,
+                                 anchors, B, n_anchors, num_base_anchors, fused_layout, score_thr, iou_thr, max_det, boxes, dims,
+                                 scores, labels, orientations, anchor_index, counts, workspace, workspace_bytes, stream);
 }

@@ -19,8 +19,10 @@ struct Lanes {
     int init()
     {
         if (ready) return GPP_OK;
+        int lo = 0, hi = 0;                             // side lanes carry the short latency-bound chains: let their workgroups in first
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         for (int l = 0; l < kLanes; ++l) {
-            hipError_t e = hipStreamCreateWithFlags(&stream[l], hipStreamNonBlocking);
+            hipError_t e = hipStreamCreateWithPriority(&stream[l], hipStreamNonBlocking, hi);
             if (e != hipSuccess) return (int)e;
             e = hipEventCreateWithFlags(&done[l], hipEventDisableTiming);
             if (e != hipSuccess) return (int)e;
@@ -45,7 +47,7 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
         gpp_plan_op op = ops[i];
         if (!op.desc) return GPP_ERR_BAD_ARG;
         const int lane = (op.kind >> 8) & 0xff;
-        const bool join = (op.kind & GPP_OP_JOIN) != 0;
+        const bool join = (op.kind & GPP_OP_JOIN) != 0, sync = (op.kind & GPP_OP_SYNC) != 0;
         op.kind &= 0xff;
         if (lane > kLanes) return GPP_ERR_BAD_ARG;
         hipStream_t st = main_st;
@@ -53,7 +55,7 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
             int rc = g_lanes.init();
             if (rc != GPP_OK) return rc;
             st = g_lanes.stream[lane - 1];
-            if (!active[lane - 1]) {                    // fork: the lane starts after everything enqueued on the main stream so far
+            if (!active[lane - 1] || sync) {            // fork: the lane starts after everything enqueued on the main stream so far
                 hipError_t e = hipEventRecord(g_lanes.fork, main_st);
                 if (e == hipSuccess) e = hipStreamWaitEvent(st, g_lanes.fork, 0);
                 if (e != hipSuccess) return (int)e;
@@ -105,6 +107,18 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
                                 d->num_base_anchors, d->fused_layout, d->score_thr, d->iou_thr, d->max_det, d->boxes, d->dims,
                                 d->scores, d->labels, d->orientations, d->anchor_index, d->counts, d->workspace,
                                 d->workspace_bytes, stream);
+            break;
+        }
+        case GPP_OP_DETECT_CANDIDATES:
+        case GPP_OP_DETECT_SELECT:
+        case GPP_OP_DETECT_EMIT: {
+            const gpp_detect_desc* d = (const gpp_detect_desc*)op.desc;
+            const int stages = op.kind == GPP_OP_DETECT_CANDIDATES ? GPP_DETECT_CANDIDATES
+                             : op.kind == GPP_OP_DETECT_SELECT ? GPP_DETECT_SELECT : GPP_DETECT_EMIT;
+            rc = gpp_detect_stages_f32(stages, d->cls_logits, d->regression, d->regression_dim, d->anchors, d->B, d->n_anchors,
+                                       d->num_base_anchors, d->fused_layout, d->score_thr, d->iou_thr, d->max_det, d->boxes,
+                                       d->dims, d->scores, d->labels, d->orientations, d->anchor_index, d->counts, d->workspace,
+                                       d->workspace_bytes, stream);
             break;
         }
         case GPP_OP_POLL: {

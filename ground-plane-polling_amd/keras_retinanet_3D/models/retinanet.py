@@ -77,7 +77,9 @@ class TailDesc(ctypes.Structure):
 
 
 OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4, 5, 6, 7
-OP_JOIN = 0x10000
+OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT = 8, 9, 10
+DETECT_OPS = (OP_DETECT, OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT)
+OP_JOIN, OP_SYNC = 0x10000, 0x20000
 
 
 class Plan(object):
@@ -91,10 +93,10 @@ class Plan(object):
         self.array = None
         self.flops = 0.0
 
-    def add(self, kind, desc, name, tag=0, flops=0.0, lane=0, join=False):
+    def add(self, kind, desc, name, tag=0, flops=0.0, lane=0, join=False, sync=False):
         self.keep.append(desc)
         self.ops.append((kind, tag, desc, name, flops))
-        self.lanes.append((int(lane) << 8) | (OP_JOIN if join else 0))
+        self.lanes.append((int(lane) << 8) | (OP_JOIN if join else 0) | (OP_SYNC if sync else 0))
         self.flops += flops
 
     def finalize(self):
@@ -199,7 +201,7 @@ class RetinaNet3D(object):
         # split-K partial tiles of the under-filled deep-K layers (res5, P5..P7); reused by every launch
         # (one per stream lane: concurrent launches must not share partial tiles)
         head_lanes = os.environ.get('GPP_HEAD_LANES', '0') != '0'
-        plan.workspaces = [torch.empty((64 << 20,), dtype=torch.uint8, device=dev) for _ in range(3 if head_lanes else 1)]
+        plan.workspaces = [torch.empty((64 << 20,), dtype=torch.uint8, device=dev) for _ in range(3 if head_lanes else 2)]
         plan.workspace = plan.workspaces[0]
 
         def fmap(h, w, c, dtype=None):
@@ -316,10 +318,12 @@ class RetinaNet3D(object):
         # layer 0 of the three towers shares its input: one fused launch (C_out = 896) into a wide
         # tensor; layers 1..3 read their channel slice of it (in_pitch > C_in)
         wide, wide_maps = pyramid(896)
-        self._conv(plan, 'pyramid_towers_0', P, wide_maps, 3, pad=(1, 1), relu=True, join=True)
-
         def slice_of(maps, c0, c):
             return [C.FMap(m.buf, B, m.H, m.W, c, off=m.off + c0, bstride=m.bstride, pitch=m.pitch) for m in maps]
+
+        # (measured and rejected: the half-empty fourth 256-column tile of this 896-wide layer as its own 128-column launch
+        # on a side stream -- the two launches do not pack into each other's partial rounds, no gain)
+        self._conv(plan, 'pyramid_towers_0', P, wide_maps, 3, pad=(1, 1), relu=True, join=True)
 
         def tower(prefix, width, src, tag=0, lane=0):
             for i in range(1, 4):
@@ -332,15 +336,39 @@ class RetinaNet3D(object):
         # streams, forked after the fused first layer and joined by the decode, so that their launches fill the
         # ramp-up / tail phases of the big regression-tower kernels
         l_dim, l_cls = (1, 2) if head_lanes else (0, 0)
-        dim_t = tower('pyramid_regression_dim', 128, slice_of(wide_maps, 768, 128), lane=l_dim)
-        plan.regression_dim, dim_o = pyramid(36, torch.float32)
-        self._conv(plan, 'pyramid_regression_dim', dim_t, dim_o, 3, pad=(1, 1), out_f32=True, lane=l_dim)
-        cls_t = tower('pyramid_classification', 256, slice_of(wide_maps, 512, 256), lane=l_cls)
-        plan.cls_logits, cls_o = pyramid(96, torch.float32)
-        self._conv(plan, 'pyramid_classification', cls_t, cls_o, 3, pad=(1, 1), out_f32=True, lane=l_cls)
-        reg_t = tower('pyramid_regression', 512, slice_of(wide_maps, 0, 512), tag=1)
-        plan.regression, reg_o = pyramid(144, torch.float32)
-        self._conv(plan, 'pyramid_regression_ops', reg_t, reg_o, 3, pad=(1, 1), out_f32=True)
+        # Launch order (default, GPP_DECODE_OVERLAP=1): classification tower, regression tower, dimension tower.
+        # The detection selection (threshold + sort + greedy NMS: one workgroup per image, latency-bound, 8 of the
+        # 256 CUs) only needs the classification logits and the corner regressions, so it runs on a side stream
+        # underneath the dimension tower; the full decode of the <= 100 survivors joins when every head is done.
+        overlap = os.environ.get('GPP_DECODE_OVERLAP', '1') != '0' and not head_lanes
+        plan.decode_overlap = overlap
+
+        def dim_tower():
+            dim_t = tower('pyramid_regression_dim', 128, slice_of(wide_maps, 768, 128), lane=l_dim)
+            plan.regression_dim, dim_o = pyramid(36, torch.float32)
+            self._conv(plan, 'pyramid_regression_dim', dim_t, dim_o, 3, pad=(1, 1), out_f32=True, lane=l_dim)
+
+        def cls_tower():
+            cls_t = tower('pyramid_classification', 256, slice_of(wide_maps, 512, 256), lane=l_cls)
+            plan.cls_logits, cls_o = pyramid(96, torch.float32)
+            self._conv(plan, 'pyramid_classification', cls_t, cls_o, 3, pad=(1, 1), out_f32=True, lane=l_cls)
+
+        def reg_tower():
+            reg_t = tower('pyramid_regression', 512, slice_of(wide_maps, 0, 512), tag=1)
+            plan.regression, reg_o = pyramid(144, torch.float32)
+            self._conv(plan, 'pyramid_regression_ops', reg_t, reg_o, 3, pad=(1, 1), out_f32=True)
+
+        detect_at = {}
+        if overlap:
+            cls_tower()
+            detect_at['candidates'] = len(plan.ops)
+            reg_tower()
+            detect_at['select'] = len(plan.ops)
+            dim_tower()
+        else:
+            dim_tower()
+            cls_tower()
+            reg_tower()
 
         # ---- decode + NMS (RegressBoxes, RegressDims, FilterDetections)
         D = MAX_DETECTIONS
@@ -361,7 +389,17 @@ class RetinaNet3D(object):
                         plan.labels.data_ptr(), plan.orientations.data_ptr(), plan.anchor_index.data_ptr(),
                         plan.counts.data_ptr(), plan.detect_ws.data_ptr(), plan.detect_ws.numel(), plan.n_anchors,
                         B, anchor_utils.NUM_BASE_ANCHORS, 1, D, SCORE_THRESHOLD, NMS_THRESHOLD if self.nms else 2.0)
-        plan.add(OP_DETECT, dd, 'filtered_detections', join=True)
+        if overlap:
+            # spliced in where their inputs are complete (the descriptors need the buffers allocated above)
+            at = detect_at['select']
+            plan.ops.insert(at, (OP_DETECT_SELECT, 0, dd, 'filtered_detections/select', 0.0))
+            plan.lanes.insert(at, (1 << 8) | OP_SYNC)
+            at = detect_at['candidates']
+            plan.ops.insert(at, (OP_DETECT_CANDIDATES, 0, dd, 'filtered_detections/candidates', 0.0))
+            plan.lanes.insert(at, 1 << 8)
+            plan.add(OP_DETECT_EMIT, dd, 'filtered_detections', join=True)
+        else:
+            plan.add(OP_DETECT, dd, 'filtered_detections', join=True)
 
         # ---- ground-plane polling (FitRoadPlanes)
         plan.keypoints = torch.empty((B, D, 4, 3), dtype=f32, device=dev)
@@ -422,7 +460,7 @@ class RetinaNet3D(object):
         fresh = False
         plan.tuning = {}
         for index, (kind, _, desc, name, flops) in enumerate(plan.ops):
-            if kind in (OP_DETECT, OP_POLL):
+            if kind in DETECT_OPS or kind == OP_POLL:
                 continue
             self.run_op(plan, index)
             if kind == OP_TAIL:

@@ -226,6 +226,23 @@ int gpp_detect_f32(const float* cls_logits, const float* regression, const float
                    int32_t* anchor_index, int32_t* counts,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same work as three separately enqueueable stages (bit mask; gpp_detect_f32 = all three, in this order):
+ *   GPP_DETECT_CANDIDATES  sigmoid + fold + threshold -> candidate keys      reads cls_logits only
+ *   GPP_DETECT_SELECT      sort + greedy NMS -> survivors' keys              reads the keys + corner regressions
+ *   GPP_DETECT_EMIT        full decode of the survivors, -1 padding           reads every head tensor
+ * so that a caller can start the (latency-bound, one workgroup per image) selection as soon as the classification
+ * and regression heads are done and overlap it with the dimension head (models/retinanet.py:128-167).  All stages
+ * take the full argument list; state passes through `workspace`. */
+#define GPP_DETECT_CANDIDATES 1
+#define GPP_DETECT_SELECT 2
+#define GPP_DETECT_EMIT 4
+int gpp_detect_stages_f32(int stages, const float* cls_logits, const float* regression, const float* regression_dim,
+                          const float* anchors, int B, int64_t n_anchors, int num_base_anchors, int fused_layout,
+                          float score_thr, float iou_thr, int max_det,
+                          float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
+                          int32_t* anchor_index, int32_t* counts,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Plan execution: one call enqueues a whole predict_on_batch (every kernel of the graph that
  * models/retinanet.py:359-422 `retinanet_bbox` builds) from a host array of descriptors.
@@ -241,12 +258,17 @@ int gpp_detect_f32(const float* cls_logits, const float* regression, const float
 #define GPP_OP_DETECT 5
 #define GPP_OP_POLL 6
 #define GPP_OP_BOTTLENECK_TAIL 7
+#define GPP_OP_DETECT_CANDIDATES 8   /* gpp_detect_desc; stages of GPP_OP_DETECT, see gpp_detect_stages_f32 */
+#define GPP_OP_DETECT_SELECT 9
+#define GPP_OP_DETECT_EMIT 10
 /* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
    that forks from the caller's stream at the first op of that lane; `kind | GPP_OP_JOIN` on a lane-0 op makes it wait
    for every open lane (the end of the plan joins too).  The caller orders the ops so that each lane only depends on
    what was enqueued before its fork.  Used for the three independent head towers. */
 #define GPP_OP_LANE(l) ((l) << 8)
 #define GPP_OP_JOIN 0x10000
+/* on a side-lane op: the lane first waits for everything enqueued on the caller's stream so far (a second fork point) */
+#define GPP_OP_SYNC 0x20000
 
 typedef struct gpp_stem_desc { const float* in; const void* weight; const float* bias; void* out;
                                int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem) */

@@ -174,7 +174,8 @@ def test_split_k_matches_torch_fp32(case, split):
 
 
 ALL_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
-             1128128, 1192128, 1128256, 1192256, 256256]
+             1128128, 1192128, 1128256, 1192256, 256256,
+             128160, 192160, 1192160]                 # N-remainder tiles (4 x 1 wavefronts, 160 columns)
 
 
 def _layer(name, dtype='bf16', workspace=False):
@@ -222,7 +223,12 @@ def test_every_tile_gives_identical_results(case):
     assert bool(((base - ref).abs() <= eps * ref.abs() + 1e-3).all())
     for tile in ALL_TILES:
         out.buf.fill_(float('nan'))
-        C.run_conv(make(tile))
+        d = make(tile)
+        bn = tile % 1000
+        if -(-d.C_out // bn) * bn > d.weight_rows:              # the tile grid would read past the packed weight rows
+            assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -1
+            continue
+        C.run_conv(d)
         assert torch.equal(out.buf.float().cpu(), base), tile
 
 

@@ -126,3 +126,33 @@ def test_hip_decode_without_nms():
         for got, want in zip(out[:5], ref):
             assert helpers.bits_equal(got[b], want)
         assert np.array_equal(out[5][b].astype(np.int64), ref_idx)
+
+
+def test_stages_enqueued_separately_equal_the_single_call():
+    """ gpp_detect_stages_f32(CANDIDATES), (SELECT), (EMIT) one after the other == gpp_detect_f32 (the plan runs the
+    first two on a side stream underneath the dimension head); a bad stage mask is refused. """
+    import torch
+    from keras_retinanet_3D.backend import hip
+    from keras_retinanet_3D.layers.filter_detections import FilterDetections
+    rng = np.random.default_rng(5)
+    anchors = A.anchors_for_image((128, 416))
+    n, B = anchors.shape[0], 3
+    dev = hip.require_device()
+    t = lambda a: torch.as_tensor(a).to(dev)  # noqa: E731
+    logits = t(rng.normal(-4.2, 1.0, size=(B, n, 8)).astype(np.float32))
+    reg = t(to_fused(rng.normal(0, 1, size=(B, n, 12)).astype(np.float32)))
+    dim = t(rng.normal(0, 1, size=(B, n, 3)).astype(np.float32))
+    anc = t(anchors)
+    whole = FilterDetections(B, n, dev, fused_regression=True)
+    want = [o.cpu().numpy().copy() for o in whole(logits, reg, dim, anc) + [whole.anchor_index]]
+    assert (want[2] > 0.05).sum() > B * 20
+    split = FilterDetections(B, n, dev, fused_regression=True)
+    for o in (split.boxes, split.dimensions, split.scores):
+        o.fill_(float('nan'))
+    args = split.args(logits, reg, dim, anc) + (hip.stream_ptr(),)
+    for stage in (1, 2, 4):
+        hip.check(hip.lib().gpp_detect_stages_f32(stage, *args), 'gpp_detect_stages_f32')
+    got = [o.cpu().numpy() for o in (split.boxes, split.dimensions, split.scores, split.labels, split.orientations, split.anchor_index)]
+    for g_, w_ in zip(got, want):
+        assert helpers.bits_equal(g_, w_)
+    assert hip.lib().gpp_detect_stages_f32(0, *args) == -1 and hip.lib().gpp_detect_stages_f32(8, *args) == -1

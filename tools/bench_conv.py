@@ -60,6 +60,81 @@ if __name__ == '__main__':
             for tile in (128, 64, 96, 160, 192):
                 bench('%s t%d' % (name, tile), B, shp, cin, cout, k, tile=tile)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'newtiles':
+        rem = (128160, 128160, 128160, 128160, 192160, 1192160)
+        deep = ()
+        for name, shp, cin, cout, k, f32, res, tiles in (
+                ('reg_ops 3x3 512->144 f32', PYR, 512, 144, 3, True, False, (192128, 1192128, 128128) + rem[3:]),
+                ('cls_out 3x3 256->96 f32', PYR, 256, 96, 3, True, False, (192128, 128128, 96128) + rem[:3]),
+                ('res4 2a 1x1 1024->256', [(26, 84)], 1024, 256, 1, False, False, (96128, 64128, 128128) + deep),
+                ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3, False, False, (96128, 64128, 128128) + deep),
+                ('res4 2c 1x1 256->1024 +res', [(26, 84)], 256, 1024, 1, False, True, (64128, 96128, 128128) + deep),
+                ('res5 2a 1x1 2048->512', [(13, 42)], 2048, 512, 1, False, False, (64128, 96128) + deep),
+                ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3, False, False, (128128, 64128) + deep),
+                ('res5 2c 1x1 512->2048 +res', [(13, 42)], 512, 2048, 1, False, True, (160128, 64128) + deep),
+                ('res3 2a 1x1 512->128', [(51, 167)], 512, 128, 1, False, False, (160128, 64128) + deep)):
+            for tile in tiles:
+                bench('%s t%d' % (name, tile), B, shp, cin, cout, k, tile=tile, out_f32=f32, residual=res, iters=30)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'stamps':
+        # needs a library built with -DGPP_STAMPS (GPP_LIB=...): where does the per-tile time go?
+        import numpy as np
+        dev = torch.device('cuda')
+        for name, shp, cin, cout, k, tile, f32 in (('reg 3x3 512->512', PYR, 512, 512, 3, 256256, False),
+                                                   ('C3_reduced 1x1 512->512', PYR[:1], 512, 512, 1, 1192256, False),
+                                                   ('cls 3x3 256->256', PYR, 256, 256, 3, 1192256, False),
+                                                   ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3, 96128, False)):
+            tdt = C.torch_dtype('bf16')
+            total = sum(h * w for h, w in shp)
+            x = (torch.randn((B, total, cin), device=dev) * 0.5).to(tdt)
+            o = torch.empty((B, total, cout), device=dev, dtype=torch.float32 if f32 else tdt)
+            w = C.pack_weight((torch.randn((k, k, cin, cout)) * 0.02).numpy(), 'bf16', dev)
+            bias = torch.zeros((cout,), device=dev)
+            ins, outs, off = [], [], 0
+            for h, wd in shp:
+                ins.append(C.FMap(x, B, h, wd, cin, off=off * cin, bstride=total * cin))
+                outs.append(C.FMap(o, B, h, wd, cout, off=off * cout, bstride=total * cout))
+                off += h * wd
+            d = C.conv_desc(ins, outs, w, bias, k, k, cin, cout, pad=(k // 2, k // 2), relu=True, dtype='bf16', out_f32=f32, tile_hint=tile, diag=16 + 32)
+            stamps = torch.zeros(((1 << 16) + 1024, 8), dtype=torch.int64, device=dev)
+            d.zero_page = stamps.data_ptr()
+            for _ in range(5):
+                C.run_conv(d)
+            torch.cuda.synchronize()
+            stamps.zero_()
+            C.run_conv(d)
+            torch.cuda.synchronize()
+            st = stamps.cpu().numpy()
+            steps = st[(1 << 16):].reshape(-1)[:64 * 128].reshape(64, 128).astype(np.float64) * 0.01
+            st = st[:(1 << 16)]
+            if (steps[:, 1] > 0).any():
+                live = steps[steps[:, 1] > 0]
+                n = int((live[0] > 0).sum())
+                dd = np.diff(live[:, :n], axis=1)
+                print('   per-K-step time (us), mean over %d workgroups, steps 0..%d:' % (len(live), n - 2))
+                print('   ' + ' '.join('%.2f' % v for v in dd.mean(axis=0)))
+            st = st[st[:, 0] != 0][:, :5].astype(np.float64) * 0.01          # us
+            t0 = st[:, 0].min()
+            dur = np.diff(st, axis=1)
+            print('%s tile %d: %d workgroups, kernel span %.1f us' % (name, tile, len(st), st[:, 4].max() - t0))
+            print('   mean us  setup %.2f  main loop %.2f  epilogue issue %.2f  store drain %.2f   (whole workgroup %.2f)' %
+                  (dur[:, 0].mean(), dur[:, 1].mean(), dur[:, 2].mean(), dur[:, 3].mean(), (st[:, 4] - st[:, 0]).mean()))
+            order = np.argsort(st[:, 0])
+            starts = st[order, 0] - t0
+            ends = st[order, 4] - t0
+            print('   workgroup starts (us), percentiles 0/25/50/75/100: ' + ' '.join('%.1f' % v for v in np.percentile(starts, [0, 25, 50, 75, 100])))
+            print('   workgroup ends   (us), percentiles 0/25/50/75/100: ' + ' '.join('%.1f' % v for v in np.percentile(ends, [0, 25, 50, 75, 100])))
+            first = starts < 1.0
+            print('   first wave of workgroups: %d started within 1 us; their mean setup/main/epi/drain: %s' %
+                  (first.sum(), ' '.join('%.2f' % v for v in dur[order][first].mean(axis=0))))
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'prio':
+        for rep in range(3):
+            for diag, what in ((0, 'base'), (64, 'setprio waves 4-7')):
+                bench('reg 3x3 512 t256256 %s' % what, B, PYR, 512, 512, 3, tile=256256, diag=diag, iters=30)
+            for diag, what in ((0, 'base'), (64, 'setprio')):
+                bench('cls 3x3 256 t1192256 %s' % what, B, PYR, 256, 256, 3, tile=1192256, diag=diag, iters=30)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'big':
         for rep in range(2):
             for tile in (512, 128):

@@ -18,8 +18,8 @@ def conv_names(backbone, fused_stages=(0, 1)):
             names += ['res%s_2a' % nm] + (['res%s_br1' % nm] if b == 0 else [])
             names += ['res%s_2b+2c' % nm] if stage in fused_stages else ['res%s_2b' % nm, 'res%s_2c' % nm]
     names += ['C5_reduced', 'P5', 'P6', 'P7', 'C4_reduced', 'P4', 'C3_reduced', 'P3']
-    names += ['heads_0(fused)'] + ['dim_%d' % i for i in range(1, 4)] + ['dim_out'] + ['cls_%d' % i for i in range(1, 4)] + ['cls_out']
-    names += ['reg_%d' % i for i in range(1, 4)] + ['reg_ops']
+    names += ['heads_0(fused)'] + ['cls_%d' % i for i in range(1, 4)] + ['cls_out']
+    names += ['reg_%d' % i for i in range(1, 4)] + ['reg_ops'] + ['dim_%d' % i for i in range(1, 4)] + ['dim_out']
     return names
 
 
@@ -30,7 +30,7 @@ def short(k):
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>', k)
     if m:
         return 'igemm %sx%s w%sx%s s%s%s' % (m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), ' pipe' if m.group(7) in ('true', '1') else '')
-    for key in ('stem_mfma', 'stem_kernel', 'maxpool', 'relu', 'splitk_reduce', 'candidates', 'nms', 'canonical_planes', 'poll'):
+    for key in ('stem_mfma', 'stem_kernel', 'maxpool', 'relu', 'splitk_reduce', 'candidates', 'nms', 'emit_kernel', 'canonical_planes', 'poll'):
         if key in k:
             return key
     return k[:40]
@@ -64,7 +64,7 @@ def main(path, backbone='resnet50'):
             name = short(k)
         grp = 'stem+pool' if name in ('stem_mfma', 'stem_kernel', 'maxpool') else \
               'backbone' if name.startswith('res') else 'heads' if name[:3] in ('reg', 'dim', 'cls', 'hea') else \
-              'decode+poll' if name in ('candidates', 'nms', 'canonical_planes', 'poll') else \
+              'decode+poll' if name in ('candidates', 'nms', 'emit_kernel', 'canonical_planes', 'poll') else \
               'fpn' if name[0] in 'CP' or name == 'relu' else 'other'
         if name.startswith('  ('):
             grp = last_grp
