@@ -135,6 +135,34 @@ __device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], i
     }
 }
 
+// finish8 with the residual already in registers (prefetched): same arithmetic, so the same bits.  Full groups only.
+template <int DT>
+__device__ __forceinline__ void finish8_pre(const gpp_conv_desc& d, float (&v)[8], int n, int64_t obase, bool has_res,
+                                            const typename Elem<DT>::vec8 rv)
+{
+    using vec8 = typename Elem<DT>::vec8;
+    using scalar = typename Elem<DT>::scalar;
+    if (has_res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+    }
+    if (d.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+    }
+    if (d.out_f32) {
+        float* dst = (float*)d.out + obase + n;
+        *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+        scalar* dst = (scalar*)d.out + obase + n;
+        vec8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (scalar)v[e];
+        *(vec8*)dst = ov;
+    }
+}
+
 // Where output row m of a group lives (and its residual row).
 struct RowAddr { int64_t obase; int64_t rbase; };
 __device__ __forceinline__ RowAddr row_addr(const gpp_conv_desc& d, int m, int HoWo, int W_out, int H_out, int H_res, int W_res,
@@ -555,6 +583,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int mt = xcd_remap(blockIdx.x, gridDim.x);
+    const gpp_conv_desc& d = d1;                                           // (GPP_STAMP reads d.reserved / d.zero_page)
+    (void)d;
+    GPP_STAMP(0);
     const gpp_conv_group& G1 = d1.groups[0];
     const gpp_conv_group& G2 = d2.groups[0];
     const int H = G1.H_out, W = G1.W_out, HW = H * W;
@@ -627,6 +658,28 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
         ++issued;
         ibuf ^= 1;
     };
+    // The shortcut rows of output tile t (phase 2) are fetched into registers long before they are used: tile 0's right
+    // here, in flight underneath the whole 3x3 phase; tile t+1's under tile t's epilogue stores.  When the epilogue
+    // issued them itself (load -> wait -> add -> store, twice per workgroup) it was the longest phase of this HBM-bound
+    // kernel: 20.7 of 29.8 us per workgroup at C = 64.
+    RowAddr ra[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+        ra[i] = row_addr(d2, m < Mg ? m : 0, HW, W, H, G2.H_res, G2.W_res, G2.out_off, G2.out_bstride, G2.res_off, G2.res_bstride);
+    }
+    const scalar* res = (const scalar*)d2.residual;
+    vec8 rpre[MF][NF2 / 2];
+    auto prefetch_res = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NF2 / 2; ++jj) {
+                const int n = t * 128 + wn * 64 + jj * 32 + fq * 8;
+                rpre[i][jj] = *(const vec8*)(res + ra[i].rbase + n);       // rows past the end were clamped to row 0: a valid address
+            }
+    };
+    if (res) prefetch_res(0);
     issue_next();
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -649,6 +702,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
         }
     }
 
+    GPP_STAMP(1);
     // ---- hand-over: everyone is done with the ring; W2 tile 0 starts streaming in while the
     // intermediate tile is written (bias, ReLU, rounded to the storage type) in A-operand layout
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -692,14 +746,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
         }
     }
 
+    GPP_STAMP(2);
     // ---- phase 2: y tile = T (BM x CMID) * W2^T, 128 output channels at a time
-    RowAddr ra[MF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + frow;
-        ra[i] = row_addr(d2, m < Mg ? m : 0, HW, W, H, G2.H_res, G2.W_res, G2.out_off, G2.out_bstride, G2.res_off, G2.res_bstride);
-    }
-    const scalar* res = (const scalar*)d2.residual;
     const int n2_tiles = d2.C_out / 128;
     for (int t = 0; t < n2_tiles; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -731,6 +779,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
             asm volatile("" ::: "memory");
             stage_w2(t + 1);                                           // streams in under the epilogue below
         }
+        // bias + shortcut + ReLU into the accumulators (this consumes rpre), then refill rpre for the next tile, then store
+        float outv[MF][NF2 / 2][8];
 #pragma unroll
         for (int jj = 0; jj < NF2 / 2; ++jj) {
             const int n = t * 128 + wn * 64 + jj * 32 + fq * 8;
@@ -739,18 +789,34 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
             for (int e = 0; e < 8; ++e) bias_v[e] = d2.bias ? d2.bias[n + e] : 0.0f;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
-                const int m = m0 + wm * (BM / WM) + i * 16 + frow;
-                if (m >= Mg) continue;
-                float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc2[i][2 * jj][e] + bias_v[e];
-                    v[4 + e] = acc2[i][2 * jj + 1][e] + bias_v[4 + e];
+                    outv[i][jj][e] = acc2[i][2 * jj][e] + bias_v[e];
+                    outv[i][jj][4 + e] = acc2[i][2 * jj + 1][e] + bias_v[4 + e];
                 }
-                finish8<DT>(d2, v, n, ra[i].obase, res ? res + ra[i].rbase : nullptr);
+                if (res) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) outv[i][jj][e] += (float)rpre[i][jj][e];
+                }
+            }
+        }
+        if (res && t + 1 < n2_tiles) prefetch_res(t + 1);
+#pragma unroll
+        for (int jj = 0; jj < NF2 / 2; ++jj) {
+            const int n = t * 128 + wn * 64 + jj * 32 + fq * 8;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+                if (m >= Mg) continue;
+                finish8_pre<DT>(d2, outv[i][jj], n, ra[i].obase, false, rpre[i][jj]);
             }
         }
     }
+    GPP_STAMP(3);
+#ifdef GPP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GPP_STAMP(4);
 }
 
 // One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.

@@ -135,6 +135,50 @@ if __name__ == '__main__':
             for diag, what in ((0, 'base'), (64, 'setprio')):
                 bench('cls 3x3 256 t1192256 %s' % what, B, PYR, 256, 256, 3, tile=1192256, diag=diag, iters=30)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'stamps_tail':
+        # phase timeline of the fused bottleneck tail (library built with -DGPP_STAMPS)
+        import ctypes
+        import numpy as np
+        from keras_retinanet_3D.backend import hip
+        dev = torch.device('cuda')
+        tdt = C.torch_dtype('bf16')
+        for cmid, H, W in ((64, 101, 334), (128, 51, 167)):
+            cout = 4 * cmid
+            a = C.FMap((torch.randn((B, H, W, cmid), device=dev) * 0.5).to(tdt), B, H, W, cmid)
+            mid = C.FMap.empty(B, H, W, cmid, tdt, dev)
+            y = C.FMap.empty(B, H, W, cout, tdt, dev)
+            sc = C.FMap((torch.randn((B, H, W, cout), device=dev) * 0.5).to(tdt), B, H, W, cout)
+            w1 = C.pack_weight((torch.randn((3, 3, cmid, cmid)) * 0.05).numpy(), 'bf16', dev)
+            w2 = C.pack_weight((torch.randn((1, 1, cmid, cout)) * 0.1).numpy(), 'bf16', dev)
+            b1, b2 = torch.zeros((cmid,), device=dev), torch.zeros((cout,), device=dev)
+            for rows in (96, 128, 160):
+                d1 = C.conv_desc([a], [mid], w1, b1, 3, 3, cmid, cmid, pad=(1, 1), relu=True, dtype='bf16', diag=16)
+                d2 = C.conv_desc([mid], [y], w2, b2, 1, 1, cmid, cout, relu=True, residuals=[sc], dtype='bf16')
+                stamps = torch.zeros((1 << 16, 8), dtype=torch.int64, device=dev)
+                d1.zero_page = stamps.data_ptr()
+                run = lambda: hip.check(hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), rows, hip.stream_ptr()), 'tail')  # noqa: E731
+                for _ in range(5):
+                    run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                stamps.zero_()
+                run()
+                torch.cuda.synchronize()
+                st = stamps.cpu().numpy()
+                st = st[st[:, 0] != 0][:, :5].astype(np.float64) * 0.01
+                dur = np.diff(st, axis=1)
+                t0 = st[:, 0].min()
+                print('tail C=%d %dx%d rows %d: %.1f us per launch (20 back to back); %d workgroups, span %.1f us' %
+                      (cmid, H, W, rows, e0.elapsed_time(e1) * 50.0, len(st), st[:, 4].max() - t0))
+                print('   mean us  phase 1 (3x3) %.2f  hand-over %.2f  phase 2 (1x1 + residual + stores) %.2f  drain %.2f  whole %.2f' %
+                      (dur[:, 0].mean(), dur[:, 1].mean(), dur[:, 2].mean(), dur[:, 3].mean(), (st[:, 4] - st[:, 0]).mean()))
+                print('   starts pct 0/25/50/75/100: ' + ' '.join('%.1f' % v for v in np.percentile(st[:, 0] - t0, [0, 25, 50, 75, 100])))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'big':
         for rep in range(2):
             for tile in (512, 128):
