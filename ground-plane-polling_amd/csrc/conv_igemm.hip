@@ -562,14 +562,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const gpp_conv_desc 
 // write + one read of the intermediate map (2 x 34.5 MB per res2 block at B = 8) on layers that are
 // HBM-bound; results are bit-identical to the two separate launches (same K order, same rounding).
 // d1 = descriptor of the 3x3 layer (its `out` is not written), d2 = descriptor of the 1x1 layer.
-template <int DT, int BM, int CMID>
-__global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2)
+//
+// NEXT = true additionally computes the FIRST layer of the following bottleneck, z = relu(W3 * y + b3) (1x1, 4*CMID ->
+// CMID, "branch2a" of the next identity block, descriptor d3): in phase 2 every wavefront then owns BM/4 full rows of
+// the y tile (4 x 1 layout), and after bias + shortcut + ReLU + rounding its registers hold exactly the MFMA activation
+// fragments of those rows (lane (q, c): pixel c, 8 consecutive channels 8q..8q+7 of a 32-channel slice), so y feeds
+// the next matrix product straight from registers while it is being stored; W3 fragments come from L2 one slice ahead.
+// Channel slices are consumed in ascending order, the order of the stand-alone layer's K-steps: z is bit-identical to
+// launching that layer on the stored y.  Saves that launch and its read of y (138 MB per res2 block at B = 8).
+template <int DT, int BM, int CMID, bool NEXT>
+__global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2, const gpp_conv_desc d3)
 {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
     using scalar = typename E::scalar;
     constexpr int WM = 2, WN = 2, NW = 4;
-    constexpr int MF = BM / WM / 16, NF1 = CMID / WN / 16, NF2 = 4;       // phase 2: BM x 128 output tiles
+    constexpr int P2M = NEXT ? 4 : 2, P2N = NEXT ? 1 : 2;                  // wavefront layout of phase 2
+    constexpr int MF = BM / WM / 16, NF1 = CMID / WN / 16;
+    constexpr int MF2 = BM / P2M / 16, NF2 = 128 / P2N / 16, COLS2 = 128 / P2N;   // phase 2: BM x 128 output tiles
+    constexpr int NZ = CMID / 16;                                          // phase 3: 16-channel tiles of z
+    static_assert(BM % (16 * P2M) == 0, "phase-2 wave tile");
     constexpr int KC = CMID / 64;                                          // 64-channel chunks of the intermediate
     constexpr int A_BYTES = BM * kRowBytes, B_BYTES = CMID * kRowBytes, STAGE = A_BYTES + B_BYTES;
     constexpr int A_IT = BM / 8 / NW, B_IT = CMID / 8 / NW, PER_STAGE = A_IT + B_IT;
@@ -627,13 +639,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
         for (int i = 0; i < A_IT; ++i) a_voff[i] = ((a_mask[i] & need) == need) ? a_base[i] + delta : kOutOfRange;
     };
     const int frow = lane & 15, fq = lane >> 4;
-    int a_rd[2], b1_rd[2], b2_rd[2];
+    const int wm2 = wave / P2N, wn2 = wave % P2N;
+    int a_rd[2], b1_rd[2], a_rd2[2], b2_rd[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int sw = ((kk * 4 + fq) ^ (frow & 7)) << 4;
         a_rd[kk] = (wm * (BM / WM) + frow) * kRowBytes + sw;
         b1_rd[kk] = A_BYTES + (wn * (CMID / WN) + frow) * kRowBytes + sw;
-        b2_rd[kk] = T_BYTES + (wn * 64 + frow) * kRowBytes + sw;
+        a_rd2[kk] = (wm2 * (BM / P2M) + frow) * kRowBytes + sw;
+        b2_rd[kk] = T_BYTES + (wn2 * COLS2 + frow) * kRowBytes + sw;
     }
     f32x4 acc1[MF][NF1];
 #pragma unroll
@@ -662,20 +676,20 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
     // here, in flight underneath the whole 3x3 phase; tile t+1's under tile t's epilogue stores.  When the epilogue
     // issued them itself (load -> wait -> add -> store, twice per workgroup) it was the longest phase of this HBM-bound
     // kernel: 20.7 of 29.8 us per workgroup at C = 64.
-    RowAddr ra[MF];
+    RowAddr ra[MF2];
 #pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+    for (int i = 0; i < MF2; ++i) {
+        const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
         ra[i] = row_addr(d2, m < Mg ? m : 0, HW, W, H, G2.H_res, G2.W_res, G2.out_off, G2.out_bstride, G2.res_off, G2.res_bstride);
     }
     const scalar* res = (const scalar*)d2.residual;
-    vec8 rpre[MF][NF2 / 2];
+    vec8 rpre[MF2][NF2 / 2];
     auto prefetch_res = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < MF; ++i)
+        for (int i = 0; i < MF2; ++i)
 #pragma unroll
             for (int jj = 0; jj < NF2 / 2; ++jj) {
-                const int n = t * 128 + wn * 64 + jj * 32 + fq * 8;
+                const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
                 rpre[i][jj] = *(const vec8*)(res + ra[i].rbase + n);       // rows past the end were clamped to row 0: a valid address
             }
     };
@@ -749,27 +763,44 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
     GPP_STAMP(2);
     // ---- phase 2: y tile = T (BM x CMID) * W2^T, 128 output channels at a time
     const int n2_tiles = d2.C_out / 128;
+    // phase 3 state (NEXT): z accumulators and the W3 fragments of the current 32-channel slice (lane (q, r): stored row
+    // 16*j + r of W3, bytes of channels slice*32 + 8q .. 8q+7), fetched from L2 one slice ahead
+    f32x4 zacc[NEXT ? MF2 : 1][NEXT ? NZ : 1];
+    vec8 w3f[NEXT ? NZ : 1];
+    const scalar* w3 = (const scalar*)d3.weight;
+    const int K3 = d3.C_in;
+    auto load_w3 = [&](vec8 (&dst)[NEXT ? NZ : 1], int slice) {
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) dst[j] = *(const vec8*)(w3 + (int64_t)(j * 16 + frow) * K3 + slice * 32 + fq * 8);
+    };
+    if constexpr (NEXT) {
+#pragma unroll
+        for (int i = 0; i < MF2; ++i)
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        load_w3(w3f, 0);
+    }
     for (int t = 0; t < n2_tiles; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                  // W2 tile t (and, for t = 0, T) is in LDS
         asm volatile("" ::: "memory");
-        f32x4 acc2[MF][NF2];
+        f32x4 acc2[MF2][NF2];
 #pragma unroll
-        for (int i = 0; i < MF; ++i)
+        for (int i = 0; i < MF2; ++i)
 #pragma unroll
             for (int j = 0; j < NF2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                vec8 af[MF], bfr[NF2];
+                vec8 af[MF2], bfr[NF2];
 #pragma unroll
-                for (int i = 0; i < MF; ++i) af[i] = *(const vec8*)(smem + kc * A_BYTES + a_rd[kk] + i * 16 * kRowBytes);
+                for (int i = 0; i < MF2; ++i) af[i] = *(const vec8*)(smem + kc * A_BYTES + a_rd2[kk] + i * 16 * kRowBytes);
 #pragma unroll
                 for (int j = 0; j < NF2; ++j) bfr[j] = *(const vec8*)(smem + kc * 128 * kRowBytes + b2_rd[kk] + j * 16 * kRowBytes);
 #pragma unroll
-                for (int i = 0; i < MF; ++i)
+                for (int i = 0; i < MF2; ++i)
 #pragma unroll
                     for (int j = 0; j < NF2; ++j) acc2[i][j] = E::mfma(bfr[j], af[i], acc2[i][j]);
             }
@@ -780,15 +811,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
             stage_w2(t + 1);                                           // streams in under the epilogue below
         }
         // bias + shortcut + ReLU into the accumulators (this consumes rpre), then refill rpre for the next tile, then store
-        float outv[MF][NF2 / 2][8];
+        float outv[MF2][NF2 / 2][8];
 #pragma unroll
         for (int jj = 0; jj < NF2 / 2; ++jj) {
-            const int n = t * 128 + wn * 64 + jj * 32 + fq * 8;
+            const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
             float bias_v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bias_v[e] = d2.bias ? d2.bias[n + e] : 0.0f;
 #pragma unroll
-            for (int i = 0; i < MF; ++i) {
+            for (int i = 0; i < MF2; ++i) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     outv[i][jj][e] = acc2[i][2 * jj][e] + bias_v[e];
@@ -798,17 +829,64 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
 #pragma unroll
                     for (int e = 0; e < 8; ++e) outv[i][jj][e] += (float)rpre[i][jj][e];
                 }
+                if (NEXT && d2.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) outv[i][jj][e] = fmaxf(outv[i][jj][e], 0.0f);
+                }
             }
         }
         if (res && t + 1 < n2_tiles) prefetch_res(t + 1);
+        if constexpr (NEXT) {
+            // phase 3: the rounded y values are the activation fragments of the next 1x1 layer
+#pragma unroll
+            for (int jj = 0; jj < NF2 / 2; ++jj) {
+                const int slice = t * (NF2 / 2) + jj;
+                vec8 w3n[NZ];
+                if (slice + 1 < n2_tiles * (NF2 / 2)) load_w3(w3n, slice + 1);
+#pragma unroll
+                for (int i = 0; i < MF2; ++i) {
+                    vec8 yf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) yf[e] = (scalar)outv[i][jj][e];
+#pragma unroll
+                    for (int j = 0; j < NZ; ++j) zacc[i][j] = E::mfma(w3f[j], yf, zacc[i][j]);
+                }
+#pragma unroll
+                for (int j = 0; j < NZ; ++j) w3f[j] = w3n[j];
+            }
+        }
 #pragma unroll
         for (int jj = 0; jj < NF2 / 2; ++jj) {
-            const int n = t * 128 + wn * 64 + jj * 32 + fq * 8;
+            const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
 #pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+            for (int i = 0; i < MF2; ++i) {
+                const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
                 if (m >= Mg) continue;
                 finish8_pre<DT>(d2, outv[i][jj], n, ra[i].obase, false, rpre[i][jj]);
+            }
+        }
+    }
+    if constexpr (NEXT) {
+        // z = relu(zacc + b3): pairs of 16-row W3 tiles give every lane 8 consecutive output channels, as everywhere
+        const gpp_conv_group& G3 = d3.groups[0];
+#pragma unroll
+        for (int q = 0; q < NZ / 2; ++q) {
+            const int n3 = q * 32 + fq * 8;
+            float bias_v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias_v[e] = d3.bias ? d3.bias[n3 + e] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < MF2; ++i) {
+                const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
+                if (m >= Mg) continue;
+                const int b = m / HW, p = m - b * HW;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = zacc[i][2 * q][e] + bias_v[e];
+                    v[4 + e] = zacc[i][2 * q + 1][e] + bias_v[4 + e];
+                }
+                finish8_pre<DT>(d3, v, n3, G3.out_off + (int64_t)b * G3.out_bstride + (int64_t)p * d3.out_pitch, false, w3f[0]);
             }
         }
     }
@@ -949,12 +1027,12 @@ int validate(const gpp_conv_desc& d)
     return GPP_OK;
 }
 
-template <int DT, int BM, int CMID>
-int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, hipStream_t st)
+template <int DT, int BM, int CMID, bool NEXT>
+int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, hipStream_t st)
 {
     constexpr int lds = 2 * (BM + CMID) * kRowBytes;
     static bool configured = false;
-    auto kernel = bottleneck_tail_kernel<DT, BM, CMID>;
+    auto kernel = bottleneck_tail_kernel<DT, BM, CMID, NEXT>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
@@ -969,27 +1047,33 @@ int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, hipStream_t st)
     d1.weight_bytes = (int32_t)w1_bytes;
     d2.weight_bytes = (int32_t)w2_bytes;
     const int64_t rows = (int64_t)d1.batch * G.H_out * G.W_out;
-    kernel<<<dim3((unsigned)((rows + BM - 1) / BM)), dim3(256), lds, st>>>(d1, d2);
+    kernel<<<dim3((unsigned)((rows + BM - 1) / BM)), dim3(256), lds, st>>>(d1, d2, d3);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }
 
 template <int DT>
-int dispatch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st)
+int dispatch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc* d3, int tile_rows, hipStream_t st)
 {
     const bool c64 = d1.C_in == 64;
+    if (d3) {                            // + first layer of the next block: phase 2 is 4 x 1 wavefronts, BM / 4 rows each
+        switch (tile_rows) {
+            case 64: return c64 ? launch_tail<DT, 64, 64, true>(d1, d2, *d3, st) : launch_tail<DT, 64, 128, true>(d1, d2, *d3, st);
+            case 0: return c64 ? launch_tail<DT, 128, 64, true>(d1, d2, *d3, st) : launch_tail<DT, 64, 128, true>(d1, d2, *d3, st);
+            case 128: return c64 ? launch_tail<DT, 128, 64, true>(d1, d2, *d3, st) : GPP_ERR_UNSUPPORTED;   // C = 128: 64 rows only (registers)
+            default: return GPP_ERR_BAD_ARG;
+        }
+    }
     switch (tile_rows) {
-        case 96: return c64 ? launch_tail<DT, 96, 64>(d1, d2, st) : launch_tail<DT, 96, 128>(d1, d2, st);
+        case 96: return c64 ? launch_tail<DT, 96, 64, false>(d1, d2, d2, st) : launch_tail<DT, 96, 128, false>(d1, d2, d2, st);
         case 0:
-        case 128: return c64 ? launch_tail<DT, 128, 64>(d1, d2, st) : launch_tail<DT, 128, 128>(d1, d2, st);
-        case 160: return c64 ? launch_tail<DT, 160, 64>(d1, d2, st) : launch_tail<DT, 160, 128>(d1, d2, st);
+        case 128: return c64 ? launch_tail<DT, 128, 64, false>(d1, d2, d2, st) : launch_tail<DT, 128, 128, false>(d1, d2, d2, st);
+        case 160: return c64 ? launch_tail<DT, 160, 64, false>(d1, d2, d2, st) : launch_tail<DT, 160, 128, false>(d1, d2, d2, st);
         default: return GPP_ERR_BAD_ARG;
     }
 }
 
-}  // namespace
-
-extern "C" int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream)
+int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const gpp_conv_desc* next1x1, int tile_rows, void* stream)
 {
     if (!conv3x3 || !conv1x1) return GPP_ERR_BAD_ARG;
     gpp_conv_desc d1 = *conv3x3, d2 = *conv1x1;
@@ -1006,7 +1090,35 @@ extern "C" int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_
     if (G1.H_in != G1.H_out || G1.W_in != G1.W_out || G2.H_out != G1.H_out || G2.W_out != G1.W_out || G2.H_in != G1.H_out || G2.W_in != G1.W_out)
         return GPP_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    return d1.dtype == GPP_BF16 ? dispatch_tail<GPP_BF16>(d1, d2, tile_rows, st) : dispatch_tail<GPP_F16>(d1, d2, tile_rows, st);
+    gpp_conv_desc d3;
+    if (next1x1) {
+        // the following block's first layer: 1x1 / stride 1 / 4C -> C on the map this launch writes, bias + ReLU, 16-bit output
+        d3 = *next1x1;
+        rc = validate(d3);
+        if (rc != GPP_OK) return rc;
+        const gpp_conv_group& G3 = d3.groups[0];
+        if (d3.dtype != d2.dtype || d3.n_groups != 1 || d3.batch != d2.batch || d3.residual || d3.out_f32 || d2.out_f32) return GPP_ERR_UNSUPPORTED;
+        if (d3.KH != 1 || d3.KW != 1 || d3.stride != 1 || d3.pad_top != 0 || d3.pad_left != 0) return GPP_ERR_UNSUPPORTED;
+        if (d3.C_in != d2.C_out || d3.C_out != d1.C_in || d3.weight_rows < d3.C_out) return GPP_ERR_UNSUPPORTED;
+        if (d3.in != d2.out || G3.in_off != G2.out_off || G3.in_bstride != G2.out_bstride || d3.in_pitch != d2.out_pitch) return GPP_ERR_BAD_ARG;
+        if (G3.H_in != G2.H_out || G3.W_in != G2.W_out || G3.H_out != G2.H_out || G3.W_out != G2.W_out) return GPP_ERR_BAD_ARG;
+    }
+    return d1.dtype == GPP_BF16 ? dispatch_tail<GPP_BF16>(d1, d2, next1x1 ? &d3 : nullptr, tile_rows, st)
+                                : dispatch_tail<GPP_F16>(d1, d2, next1x1 ? &d3 : nullptr, tile_rows, st);
+}
+
+}  // namespace
+
+extern "C" int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream)
+{
+    return tail_entry(conv3x3, conv1x1, nullptr, tile_rows, stream);
+}
+
+extern "C" int gpp_bottleneck_tail_next(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const gpp_conv_desc* next1x1,
+                                        int tile_rows, void* stream)
+{
+    if (!next1x1) return GPP_ERR_BAD_ARG;
+    return tail_entry(conv3x3, conv1x1, next1x1, tile_rows, stream);
 }
 
 extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)

@@ -76,8 +76,14 @@ class TailDesc(ctypes.Structure):
     _fields_ = [('conv3x3', ctypes.c_void_p), ('conv1x1', ctypes.c_void_p), ('tile_rows', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class TailNextDesc(ctypes.Structure):
+    _fields_ = [('conv3x3', ctypes.c_void_p), ('conv1x1', ctypes.c_void_p), ('next1x1', ctypes.c_void_p),
+                ('tile_rows', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4, 5, 6, 7
 OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT = 8, 9, 10
+OP_TAIL_NEXT = 11
 DETECT_OPS = (OP_DETECT, OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT)
 OP_JOIN, OP_SYNC = 0x10000, 0x20000
 
@@ -89,6 +95,7 @@ class Plan(object):
         self.keep = []          # ctypes descriptors and torch buffers kept alive
         self.io = {}            # conv op name -> (input FMaps, output FMaps, residual FMaps or None)
         self.ops = []           # (kind, tag, desc, name, flops)
+        self.oracle_names = {}  # fused ops: reference layer name of each output map (per-layer parity tests)
         self.lanes = []         # per op: side-stream lane << 8 | join flag (include/gpp.h GPP_OP_LANE / GPP_OP_JOIN)
         self.array = None
         self.flops = 0.0
@@ -183,16 +190,28 @@ class RetinaNet3D(object):
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
-    def _tail(self, plan, nm, a, y, shortcut):
+    def _tail(self, plan, nm, a, y, shortcut, nxt=None):
         """ branch2b (3x3) + branch2c (1x1, + shortcut, ReLU) of one bottleneck as ONE launch
-        (gpp_bottleneck_tail): the intermediate map never reaches HBM.  Bit-identical to the two layers. """
+        (gpp_bottleneck_tail): the intermediate map never reaches HBM.  Bit-identical to the two layers.
+        nxt = (name of the following identity block, its branch2a output map): that block's first 1x1 layer is computed
+        by the same launch from the y tile while it is being stored (gpp_bottleneck_tail_next), bit-identical too. """
         d1 = self._desc(plan, 'res{}_branch2b'.format(nm), [a], [a], 3, pad=(1, 1), relu=True)       # its `out` is never written
         d2 = self._desc(plan, 'res{}_branch2c'.format(nm), [a], [y], 1, relu=True, residuals=[shortcut])
         plan.keep += [d1, d2]
-        t = TailDesc(ctypes.addressof(d1), ctypes.addressof(d2), 0, 0)
-        name = 'res{}_branch2b+2c'.format(nm)
-        plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2))
-        plan.io[name] = ([a], [y], [shortcut])
+        if nxt is None:
+            t = TailDesc(ctypes.addressof(d1), ctypes.addressof(d2), 0, 0)
+            name = 'res{}_branch2b+2c'.format(nm)
+            plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2))
+            plan.io[name] = ([a], [y], [shortcut])
+            return
+        nm_next, a_next = nxt
+        d3 = self._desc(plan, 'res{}_branch2a'.format(nm_next), [y], [a_next], 1, relu=True)
+        plan.keep.append(d3)
+        t = TailNextDesc(ctypes.addressof(d1), ctypes.addressof(d2), ctypes.addressof(d3), 0, 0)
+        name = 'res{}_branch2b+2c+res{}_branch2a'.format(nm, nm_next)
+        plan.add(OP_TAIL_NEXT, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2) + C.conv_flops(d3))
+        plan.io[name] = ([a], [y, a_next], [shortcut])
+        plan.oracle_names[name] = ['res{}_branch2c'.format(nm), 'res{}_branch2a'.format(nm_next)]
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
         torch, dev, dt = self.torch, self.device, self.tdtype
@@ -236,6 +255,12 @@ class RetinaNet3D(object):
         # faster than its two layers -- 122 us vs 36 + 80 -- but the step is: 69 MB less through HBM per block)
         fuse_tail = [int(v) for v in os.environ.get('GPP_FUSE_TAIL', '64,128').split(',') if v.strip() and int(v) > 0]
 
+        # GPP_FUSE_NEXT=1: additionally the first 1x1 layer of the FOLLOWING identity block in the same launch
+        # (gpp_bottleneck_tail_next: y feeds the next product from registers, bit-identical).  Off by default -- measured
+        # slower than the separate launch (C = 64: 137 us vs 92 + 36; C = 128: 151 vs 55 + 24): every wavefront re-reads all
+        # of W3 from L2 and the 250-register kernel drops to two workgroups per CU (tools/bench_conv.py stamps_tail)
+        fuse_next = os.environ.get('GPP_FUSE_NEXT', '0') != '0'
+
         def sub(fm, c0, nb):
             return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch)
 
@@ -257,17 +282,24 @@ class RetinaNet3D(object):
             for c0 in range(0, B, chunk):
                 nb = min(chunk, B - c0)
                 xs = sub(xin, c0, nb)
-                for rec in blocks:
+                have_2a = False                  # branch2a of this block already computed by the previous block's launch
+                for bi, rec in enumerate(blocks):
                     nm, stride = rec['nm'], rec['stride']
                     a_, y_ = sub(rec['a'], c0, nb), sub(rec['y'], c0, nb)
-                    self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True)
+                    if not have_2a:
+                        self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True)
+                    have_2a = False
                     if rec['sc'] is not None:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride)
                     else:
                         sc_ = xs
                     if rec['b'] is None:
-                        self._tail(plan, nm, a_, y_, sc_)
+                        nxt = None
+                        if fuse_next and bi + 1 < len(blocks) and blocks[bi + 1]['b'] is None:
+                            nxt = (blocks[bi + 1]['nm'], sub(blocks[bi + 1]['a'], c0, nb))
+                            have_2a = True
+                        self._tail(plan, nm, a_, y_, sc_, nxt)
                     else:
                         b_ = sub(rec['b'], c0, nb)
                         self._conv(plan, 'res{}_branch2b'.format(nm), [a_], [b_], 3, pad=(1, 1), relu=True)
@@ -463,11 +495,12 @@ class RetinaNet3D(object):
             if kind in DETECT_OPS or kind == OP_POLL:
                 continue
             self.run_op(plan, index)
-            if kind == OP_TAIL:
+            if kind in (OP_TAIL, OP_TAIL_NEXT):
                 key = (name, B, H, Wd)
                 if key not in self._tuned:
                     times = {}
-                    for rows in (96, 128, 160):
+                    c_mid = ctypes.cast(desc.conv3x3, ctypes.POINTER(hip.ConvDesc)).contents.C_in
+                    for rows in ((96, 128, 160) if kind == OP_TAIL else ((64, 128) if c_mid == 64 else (64,))):
                         desc.tile_rows = rows
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         self.run_op(plan, index)

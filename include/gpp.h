@@ -157,6 +157,13 @@ int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* bes
    tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup.  Other shapes: GPP_ERR_UNSUPPORTED. */
 int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream);
 
+/* The same launch extended by the FIRST layer of the following identity bottleneck ("branch2a": 1x1, 4C -> C, + bias +
+   ReLU): next1x1->in must be the map conv1x1 writes.  The rounded y tile feeds the next matrix product straight from the
+   registers it is stored from; next1x1->out is bit-identical to gpp_conv2d_igemm(next1x1) run after the two-layer launch.
+   tile_rows: 0 (= 128), 64 or 128. */
+int gpp_bottleneck_tail_next(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const gpp_conv_desc* next1x1,
+                             int tile_rows, void* stream);
+
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
 
@@ -261,6 +268,7 @@ int gpp_detect_stages_f32(int stages, const float* cls_logits, const float* regr
 #define GPP_OP_DETECT_CANDIDATES 8   /* gpp_detect_desc; stages of GPP_OP_DETECT, see gpp_detect_stages_f32 */
 #define GPP_OP_DETECT_SELECT 9
 #define GPP_OP_DETECT_EMIT 10
+#define GPP_OP_BOTTLENECK_TAIL_NEXT 11   /* gpp_tail_next_desc */
 /* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
    that forks from the caller's stream at the first op of that lane; `kind | GPP_OP_JOIN` on a lane-0 op makes it wait
    for every open lane (the end of the plan joins too).  The caller orders the ops so that each lane only depends on
@@ -292,6 +300,8 @@ typedef struct gpp_poll_desc {
 } gpp_poll_desc;
 
 typedef struct gpp_tail_desc { const gpp_conv_desc* conv3x3; const gpp_conv_desc* conv1x1; int32_t tile_rows, reserved; } gpp_tail_desc;
+typedef struct gpp_tail_next_desc { const gpp_conv_desc* conv3x3; const gpp_conv_desc* conv1x1; const gpp_conv_desc* next1x1;
+                                    int32_t tile_rows, reserved; } gpp_tail_next_desc;
 
 typedef struct gpp_plan_op { int32_t kind; int32_t tag; const void* desc; } gpp_plan_op;
 

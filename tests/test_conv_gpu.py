@@ -299,3 +299,47 @@ def test_bottleneck_tail_rejects_other_shapes():
     assert hip.lib().gpp_bottleneck_tail(None, None, 0, hip.stream_ptr()) == -1
     rc = hip.lib().gpp_bottleneck_tail(ctypes.byref(make(0)), ctypes.byref(make(0)), 0, hip.stream_ptr())   # 3x3 as second half
     assert rc == -4
+
+
+@pytest.mark.parametrize('tile_rows', [0, 64, 128])
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('cmid,B,H,W', [(64, 2, 25, 31), (128, 1, 26, 21), (64, 1, 7, 5), (128, 3, 9, 40)])
+def test_bottleneck_tail_next_equals_the_three_layers(cmid, B, H, W, dtype, tile_rows):
+    """ gpp_bottleneck_tail_next (3x3 + 1x1 + shortcut + the NEXT block's first 1x1 in one launch; the y tile feeds the
+    third matrix product straight from registers) must reproduce the three separate launches bit for bit. """
+    g = torch.Generator().manual_seed(7 * cmid + H)
+    tdt = C.torch_dtype(dtype)
+    dev = torch.device('cuda')
+    cout = 4 * cmid
+    a = torch.randn((B, H, W, cmid), generator=g).to(tdt)
+    k1 = (torch.randn((3, 3, cmid, cmid), generator=g) * (2.0 / (9 * cmid)) ** 0.5).to(tdt)
+    k2 = (torch.randn((1, 1, cmid, cout), generator=g) * (2.0 / cmid) ** 0.5).to(tdt)
+    k3 = (torch.randn((1, 1, cout, cmid), generator=g) * (2.0 / cout) ** 0.5).to(tdt)
+    b1d, b2d, b3d = [(torch.randn((c,), generator=g) * 0.1).to(dev) for c in (cmid, cout, cmid)]
+    sc = C.FMap(torch.randn((B, H, W, cout), generator=g).to(tdt).to(dev).contiguous(), B, H, W, cout)
+    amap = C.FMap(a.to(dev).contiguous(), B, H, W, cmid)
+    mid = C.FMap.empty(B, H, W, cmid, tdt, dev)
+    y_sep, y_fused = C.FMap.empty(B, H, W, cout, tdt, dev), C.FMap.empty(B, H, W, cout, tdt, dev)
+    z_sep, z_fused = C.FMap.empty(B, H, W, cmid, tdt, dev), C.FMap.empty(B, H, W, cmid, tdt, dev)
+    w1, w2, w3 = [C.pack_weight(k.float().numpy(), dtype, dev) for k in (k1, k2, k3)]
+    d1 = C.conv_desc([amap], [mid], w1, b1d, 3, 3, cmid, cmid, pad=(1, 1), relu=True, dtype=dtype)
+    d2 = C.conv_desc([mid], [y_sep], w2, b2d, 1, 1, cmid, cout, relu=True, residuals=[sc], dtype=dtype)
+    d3 = C.conv_desc([y_sep], [z_sep], w3, b3d, 1, 1, cout, cmid, relu=True, dtype=dtype)
+    for d in (d1, d2, d3):
+        C.run_conv(d)
+    want_y, want_z = y_sep.buf.float().cpu(), z_sep.buf.float().cpu()
+    assert want_z.abs().max() > 0
+    d2f = C.conv_desc([mid], [y_fused], w2, b2d, 1, 1, cmid, cout, relu=True, residuals=[sc], dtype=dtype)
+    d3f = C.conv_desc([y_fused], [z_fused], w3, b3d, 1, 1, cout, cmid, relu=True, dtype=dtype)
+    y_fused.buf.fill_(float('nan'))
+    z_fused.buf.fill_(float('nan'))
+    rc = hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2f), ctypes.byref(d3f), tile_rows, hip.stream_ptr())
+    if cmid == 128 and tile_rows == 128:
+        assert rc == -4                                       # C = 128 runs with 64-row tiles only
+        return
+    hip.check(rc, 'gpp_bottleneck_tail_next')
+    assert torch.equal(y_fused.buf.float().cpu(), want_y)
+    assert torch.equal(z_fused.buf.float().cpu(), want_z)
+    # the third descriptor must read the map the second one writes
+    assert hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2f), ctypes.byref(d3), tile_rows, hip.stream_ptr()) == -1
+    assert hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2f), None, tile_rows, hip.stream_ptr()) == -1

@@ -178,6 +178,46 @@ if __name__ == '__main__':
                 print('   mean us  phase 1 (3x3) %.2f  hand-over %.2f  phase 2 (1x1 + residual + stores) %.2f  drain %.2f  whole %.2f' %
                       (dur[:, 0].mean(), dur[:, 1].mean(), dur[:, 2].mean(), dur[:, 3].mean(), (st[:, 4] - st[:, 0]).mean()))
                 print('   starts pct 0/25/50/75/100: ' + ' '.join('%.1f' % v for v in np.percentile(st[:, 0] - t0, [0, 25, 50, 75, 100])))
+            # the same tail + the next block's first 1x1 layer in one launch, against the separate launch of that layer
+            z = C.FMap.empty(B, H, W, cmid, tdt, dev)
+            w3 = C.pack_weight((torch.randn((1, 1, cout, cmid)) * 0.05).numpy(), 'bf16', dev)
+            b3 = torch.zeros((cmid,), device=dev)
+
+            def timed(fn, n=20):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1000.0 / n
+            for tile in (96064, 128064, 64128, 160128, 128128):
+                d3s = C.conv_desc([y], [z], w3, b3, 1, 1, cout, cmid, relu=True, dtype='bf16', tile_hint=tile)
+                print('   next 2a alone, tile %d: %.1f us' % (tile, timed(lambda: C.run_conv(d3s))))
+            for rows in (64, 128):
+                d1 = C.conv_desc([a], [mid], w1, b1, 3, 3, cmid, cmid, pad=(1, 1), relu=True, dtype='bf16', diag=16)
+                d2 = C.conv_desc([mid], [y], w2, b2, 1, 1, cmid, cout, relu=True, residuals=[sc], dtype='bf16')
+                d3 = C.conv_desc([y], [z], w3, b3, 1, 1, cout, cmid, relu=True, dtype='bf16')
+                stamps = torch.zeros((1 << 16, 8), dtype=torch.int64, device=dev)
+                d1.zero_page = stamps.data_ptr()
+                rc = hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), rows, hip.stream_ptr())
+                if rc != 0:
+                    continue
+                us = timed(lambda: hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), rows, hip.stream_ptr()))
+                stamps.zero_()
+                hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), rows, hip.stream_ptr())
+                torch.cuda.synchronize()
+                st = stamps.cpu().numpy()
+                st = st[st[:, 0] != 0][:, :5].astype(np.float64) * 0.01
+                msg = ''
+                if len(st):
+                    dur = np.diff(st, axis=1)
+                    msg = '; phase 1 %.2f  hand-over %.2f  phases 2+3 %.2f  drain %.2f  whole %.2f us, %d workgroups' % (
+                        dur[:, 0].mean(), dur[:, 1].mean(), dur[:, 2].mean(), dur[:, 3].mean(), (st[:, 4] - st[:, 0]).mean(), len(st))
+                print('   tail + next 2a in one launch, rows %d: %.1f us%s' % (rows, us, msg))
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'big':
         for rep in range(2):
