@@ -219,6 +219,12 @@ if __name__ == '__main__':
                         dur[:, 0].mean(), dur[:, 1].mean(), dur[:, 2].mean(), dur[:, 3].mean(), (st[:, 4] - st[:, 0]).mean(), len(st))
                 print('   tail + next 2a in one launch, rows %d: %.1f us%s' % (rows, us, msg))
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'mid':
+        # the latency-bound middle of the backbone, one launch shape each (for rocprofv3 --pmc)
+        bench('res4 2a 1x1 1024->256 t96128', B, [(26, 84)], 1024, 256, 1, tile=96128, iters=20)
+        bench('res4 2b 3x3 256->256 t96128', B, [(26, 84)], 256, 256, 3, tile=96128, iters=20)
+        bench('res5 2b 3x3 512->512 t64128', B, [(13, 42)], 512, 512, 3, tile=64128, iters=20)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'big':
         for rep in range(2):
             for tile in (512, 128):
