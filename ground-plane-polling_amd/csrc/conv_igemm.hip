@@ -934,7 +934,7 @@ int launch(gpp_conv_desc& d, hipStream_t st)
     if (d.partial && d.split_k != 1) {
         const int blocks = tiles * n_tiles;
         int want = d.split_k > 1 ? d.split_k : (blocks < 192 ? (384 + blocks - 1) / blocks : 1);
-        while (want > 1 && nk / want < 8) --want;
+        while (want > 1 && nk / want < (d.split_k > 1 ? 4 : 8)) --want;      // explicit requests (autotune) may go down to 4 K-steps per split
         const int64_t slab = (int64_t)tiles * BM * n_tiles * BN * 4;
         while (want > 1 && slab * want > (int64_t)d.partial_bytes) --want;
         nsplit = want < 1 ? 1 : want;
@@ -1152,7 +1152,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                                  1128128, 1192128, 1128256, 1192256, 256256,
                                  128160, 192160, 1192160};
-    static const int kSplits[] = {1, 2, 3, 4, 6, 8};
+    static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);
@@ -1198,7 +1198,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         const int64_t blocks = ((rows + bm - 1) / bm) * ((desc->C_out + bn - 1) / bn);
         if (blocks >= 512 || nk < 16) continue;                      // split-K only for under-filled deep-K layers
         for (int split : kSplits) {
-            if (split == 1 || nk / split < 8) continue;
+            if (split == 1 || nk / split < (split > 8 ? 4 : 8)) continue;
             // a split changes the summation order: take it only for a clear (> 3 %) win
             if (time_one(tile, split, &us) == GPP_OK && us < 0.97f * best) { best = us; best_tile = tile; best_split = split; }
         }

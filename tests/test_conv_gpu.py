@@ -244,7 +244,7 @@ def test_autotune_picks_a_valid_configuration(case):
     d = make(0, split_k=0)
     best = ctypes.c_float(-1.0)
     hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(d), 3, hip.stream_ptr(), ctypes.byref(best)), 'gpp_conv2d_autotune')
-    assert (d.tile_hint == 0 or d.tile_hint in ALL_TILES) and 0 <= d.split_k <= 8 and 0.0 < best.value < 1e5
+    assert (d.tile_hint == 0 or d.tile_hint in ALL_TILES) and 0 <= d.split_k <= 16 and 0.0 < best.value < 1e5
     out.buf.fill_(float('nan'))
     C.run_conv(d)
     got = out.buf.float().cpu()
