@@ -299,6 +299,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- shortcut prefetch (small non-pipelined tiles only: the layers that carry a residual are the 1x1 "branch2c" /
+    // FPN lateral convs with 4-16 K-steps, where load -> wait -> add -> store in the epilogue is a large part of a
+    // workgroup's life): the residual rows of this tile are requested now and are in registers when the loop ends
+    constexpr bool RESPRE = !PIPE && (MF * NF / 2 <= 10);
+    vec8 rpre[RESPRE ? MF : 1][RESPRE ? NF / 2 : 1];
+    RowAddr ra_pre[RESPRE ? MF : 1];
+    const bool use_pre = RESPRE && d.residual != nullptr && gridDim.y == 1 && (d.C_out & 7) == 0;
+    if constexpr (RESPRE) {
+        if (use_pre) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
+                ra_pre[i] = row_addr(d, m < Mg ? m : 0, HoWo, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
+#pragma unroll
+                for (int jj = 0; jj < NF / 2; ++jj) {
+                    const int n = n0 + wn * (BN / WN) + jj * 32 + (lane >> 4) * 8;
+                    rpre[i][jj] = *(const vec8*)((const scalar*)d.residual + ra_pre[i].rbase + (n < d.C_out ? n : 0));
+                }
+            }
+        }
+    }
+
     GPP_STAMP(1);
     // ---- main loop.  Ring of STAGES buffers, PF = STAGES-1 K-steps of LDS-DMA in flight; one raw
     // s_barrier per K-step.  At the top of step ks a counted vmcnt retires this wave's loads of
@@ -481,6 +503,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
         const int n = n0 + wn * COLS + jj * 32 + fq * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias_v[jj][e] = (d.bias && n + e < d.C_out) ? d.bias[n + e] : 0.0f;
+    }
+    if constexpr (RESPRE) {
+        if (use_pre) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+                if (m >= Mg) continue;
+#pragma unroll
+                for (int jj = 0; jj < NF / 2; ++jj) {
+                    const int n = n0 + wn * COLS + jj * 32 + fq * 8;
+                    if (n >= d.C_out) continue;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
+                        v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
+                    }
+                    finish8_pre<DT>(d, v, n, ra_pre[i].obase, true, rpre[i][jj]);
+                }
+            }
+            GPP_STAMP(3);
+            GPP_STAMP(4);
+            return;
+        }
     }
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
