@@ -146,6 +146,28 @@ def test_decode_overlap_does_not_change_results(monkeypatch):
             assert helpers.bits_equal(a, b)
 
 
+def test_hip_graph_capture_replays_the_plan(monkeypatch):
+    """ model.capture(plan): the whole plan, side-stream fork / join of the detection selection included, recorded into a
+    HIP graph; replays give the eager results bit for bit on new inputs """
+    monkeypatch.setenv('GPP_AUTOTUNE', '0')
+    model = models.load_model('synthetic:1234', backbone_name='resnet50')
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    P = np.tile(P_inv[None].astype(np.float32), (2, 1, 1))
+    pl = np.tile(planes[None], (2, 1, 1))
+    x0, x1 = images(2, 160, 256, seed=3), images(2, 160, 256, seed=4)
+    want0 = model.predict_on_batch([x0, P, pl])
+    want1 = model.predict_on_batch([x1, P, pl])
+    assert not all(helpers.bits_equal(a, b) for a, b in zip(want0, want1))
+    plan = model.plan_for(2, 160, 256, planes.shape[0], True)
+    assert plan.decode_overlap
+    model.capture(plan)
+    for x, want in ((x0, want0), (x1, want1), (x0, want0)):
+        got = model.predict_on_batch([x, P, pl])
+        for a, b in zip(got, want):
+            assert helpers.bits_equal(a, b)
+
+
 def test_f16_storage_runs_and_agrees_with_bf16(model50):
     batch, h, w = 1, 96, 160
     img = images(batch, h, w, seed=5)
