@@ -550,7 +550,7 @@ extern "C" int gpp_detect_stages_f32(int stages, const float* cls_logits, const 
     Layout L = {fused_layout, num_base_anchors};
     hipError_t e;
     if (stages & GPP_DETECT_CANDIDATES) {                  // needs cls_logits only
-        e = hipMemsetAsync(cnt, 0, kHeaderBytes, st);
+        e = hipMemsetAsync(cnt, 0, (size_t)B * kCounterStride, st);      // the header slots of the B images of this call
         if (e != hipSuccess) return (int)e;
         candidates_kernel<<<dim3((unsigned)((n_anchors + 255) / 256), (unsigned)B), 256, 0, st>>>(
             cls_logits, n_anchors, kstride, score_thr, keys, cnt);
