@@ -449,17 +449,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     for (int p = 0; p < PF; ++p)
         if (issued < nk) issue_next();
     int cbuf = 0;
+    // (diagnostic build: four stamps per K-step of the first 64 workgroups -- top, after the wait, after the barrier,
+    // after the LDS-DMA issue; the MFMA part runs up to the next top)
+#ifdef GPP_STAMPS
+#define GPP_KSTAMP(j)                                                                                                  \
+    do {                                                                                                               \
+        if ((d.reserved & 32) && blockIdx.x < 64 && ks < 30 && wave == 0 && lane == 0)                                 \
+            ((unsigned long long*)d.zero_page)[(1 << 19) + blockIdx.x * 128 + ks * 4 + (j)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GPP_KSTAMP(j) do { } while (0)
+#endif
     for (int ks = 0; ks < nk; ++ks) {
+        GPP_KSTAMP(0);
         if (issued - ks - 1 >= PF - 1 && PF > 1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * PER_STAGE) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GPP_KSTAMP(1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        GPP_KSTAMP(2);
         if (issued < nk) {
             if (d.reserved & 1) { ++issued; } else issue_next();      // bit 0 (diagnostic): skip the LDS-DMA
         }
+        GPP_KSTAMP(3);
         if (!(d.reserved & 2)) {                                       // bit 1 (diagnostic): skip LDS reads + MFMA
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {

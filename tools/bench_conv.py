@@ -130,9 +130,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'prio':
         for rep in range(3):
-            for diag, what in ((0, 'base'), (64, 'setprio waves 4-7')):
+            for diag, what in ((0, 'base'),):
                 bench('reg 3x3 512 t256256 %s' % what, B, PYR, 512, 512, 3, tile=256256, diag=diag, iters=30)
-            for diag, what in ((0, 'base'), (64, 'setprio')):
+            for diag, what in ((0, 'base'),):
                 bench('cls 3x3 256 t1192256 %s' % what, B, PYR, 256, 256, 3, tile=1192256, diag=diag, iters=30)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'stamps_tail':
@@ -224,6 +224,42 @@ if __name__ == '__main__':
         bench('res4 2a 1x1 1024->256 t96128', B, [(26, 84)], 1024, 256, 1, tile=96128, iters=20)
         bench('res4 2b 3x3 256->256 t96128', B, [(26, 84)], 256, 256, 3, tile=96128, iters=20)
         bench('res5 2b 3x3 512->512 t64128', B, [(13, 42)], 512, 512, 3, tile=64128, iters=20)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'kstamps':
+        # inside a K-step of the plain (non-pipelined) loop, library built with -DGPP_STAMPS
+        import numpy as np
+        dev = torch.device('cuda')
+        for name, shp, cin, cout, k, tile in (('res4 2a 1x1 1024->256', [(26, 84)], 1024, 256, 1, 96128), ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3, 96128),
+                                              ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3, 64128), ('res5 2a 1x1 2048->512', [(13, 42)], 2048, 512, 1, 64128)):
+            tdt = C.torch_dtype('bf16')
+            total = sum(h * w for h, w in shp)
+            x = (torch.randn((B, total, cin), device=dev) * 0.5).to(tdt)
+            o = torch.empty((B, total, cout), device=dev, dtype=tdt)
+            w = C.pack_weight((torch.randn((k, k, cin, cout)) * 0.02).numpy(), 'bf16', dev)
+            bias = torch.zeros((cout,), device=dev)
+            ins = [C.FMap(x, B, shp[0][0], shp[0][1], cin)]
+            outs = [C.FMap(o, B, shp[0][0], shp[0][1], cout)]
+            d = C.conv_desc(ins, outs, w, bias, k, k, cin, cout, pad=(k // 2, k // 2), relu=True, dtype='bf16', tile_hint=tile, diag=16 + 32)
+            stamps = torch.zeros(((1 << 16) + 1024, 8), dtype=torch.int64, device=dev)
+            d.zero_page = stamps.data_ptr()
+            for _ in range(20):
+                C.run_conv(d)
+            torch.cuda.synchronize()
+            stamps.zero_()
+            for _ in range(3):
+                C.run_conv(d)                       # the stamps of the last of three back-to-back launches remain
+            torch.cuda.synchronize()
+            st = stamps.cpu().numpy()[(1 << 16):].reshape(-1)[:64 * 128].reshape(64, 32, 4).astype(np.float64) * 0.01
+            live = st[st[:, 1, 0] > 0]
+            nsteps = min(30, (live[0, :, 0] > 0).sum())
+            seg = live[:, 1:nsteps - 1, :]                       # skip the first step
+            nxt = live[:, 2:nsteps, 0]
+            wait = (seg[:, :, 1] - seg[:, :, 0]).mean()
+            bar = (seg[:, :, 2] - seg[:, :, 1]).mean()
+            dma = (seg[:, :, 3] - seg[:, :, 2]).mean()
+            mma = (nxt - seg[:, :, 3]).mean()
+            print('%-24s tile %d: per K-step %.2f us = wait for the tile %.2f + barrier %.2f + LDS-DMA issue %.2f + LDS reads and MFMA %.2f  (%d workgroups, %d steps)' %
+                  (name, tile, wait + bar + dma + mma, wait, bar, dma, mma, len(live), nsteps - 2))
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'big':
         for rep in range(2):
