@@ -1248,14 +1248,14 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     for (int tile : kTiles) {
         const int bn = tile % 1000 ? tile % 1000 : 128, bm = tile ? (tile / 1000) % 1000 : 128;
         if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
-        if (bn == 256 && (desc->C_out < 192 || rows < 256 * 128)) continue;
+        if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) continue;
         if (tile > 1000000 && nk < 4) continue;                      // the pipelined loop needs a few K-steps to pay
         if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding
         float us = 0.0f;
         int r = time_one(tile, tile == 0 ? split_in : 1, &us);
         if (r != GPP_OK) { if (tile == 0) { rc = r; break; } continue; }
         if (us < best) { best = us; best_tile = tile; best_split = tile == 0 ? split_in : 1; }
-        if (tile == 0 || bn == 256 || !desc->partial) continue;
+        if (tile == 0 || !desc->partial) continue;
         const int64_t blocks = ((rows + bm - 1) / bm) * ((desc->C_out + bn - 1) / bn);
         if (blocks >= 512 || nk < 16) continue;                      // split-K only for under-filled deep-K layers
         for (int split : kSplits) {

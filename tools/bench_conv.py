@@ -261,6 +261,27 @@ if __name__ == '__main__':
             print('%-24s tile %d: per K-step %.2f us = wait for the tile %.2f + barrier %.2f + LDS-DMA issue %.2f + LDS reads and MFMA %.2f  (%d workgroups, %d steps)' %
                   (name, tile, wait + bar + dma + mma, wait, bar, dma, mma, len(live), nsteps - 2))
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'autotune':
+        # what gpp_conv2d_autotune picks (tile, split-K, us) for the under-filled deep-K layers
+        import ctypes
+        from keras_retinanet_3D.backend import hip
+        dev = torch.device('cuda')
+        ws = torch.empty((64 << 20,), dtype=torch.uint8, device=dev)
+        for name, shp, cin, cout, k in (('P4 3x3 512->512', [(26, 84)], 512, 512, 3), ('P5 3x3 512->512', [(13, 42)], 512, 512, 3),
+                                        ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3), ('C5_reduced 1x1 2048->512', [(13, 42)], 2048, 512, 1),
+                                        ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3), ('C4_reduced 1x1 1024->512', [(26, 84)], 1024, 512, 1)):
+            tdt = C.torch_dtype('bf16')
+            h, wd = shp[0]
+            x = (torch.randn((B, h * wd, cin), device=dev) * 0.5).to(tdt)
+            o = torch.empty((B, h * wd, cout), device=dev, dtype=tdt)
+            w = C.pack_weight((torch.randn((k, k, cin, cout)) * 0.02).numpy(), 'bf16', dev)
+            bias = torch.zeros((cout,), device=dev)
+            d = C.conv_desc([C.FMap(x, B, h, wd, cin)], [C.FMap(o, B, h, wd, cout)], w, bias, k, k, cin, cout, pad=(k // 2, k // 2), relu=True,
+                            dtype='bf16', workspace=ws, split_k=0)
+            best = ctypes.c_float(0.0)
+            hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(d), 16, hip.stream_ptr(), ctypes.byref(best)), 'autotune')
+            print('%-28s -> tile %8d split %2d  %.1f us' % (name, d.tile_hint, d.split_k, best.value))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'big':
         for rep in range(2):
             for tile in (512, 128):
