@@ -170,10 +170,30 @@ def main():
         ms = ctypes.c_float(0.0)
         hip.check(lib.gpp_event_elapsed_ms(events[i], events[i + 1], ctypes.byref(ms)))
         durations.append(ms.value)
-    tagged_flops = [fl for _, tag, _, _, fl in plan.ops if tag]
+    tags = [tag for _, tag, _, _, _ in plan.ops if tag]                   # per step: the tagged ops in launch order
+    by_tag = {}
+    for i, ms_ in enumerate(durations):
+        by_tag.setdefault(tags[i % len(tags)], []).append(ms_)
+    tagged_flops = [fl for _, tag, _, _, fl in plan.ops if tag == 1]       # tag 1 = the regression-tower launches
     flops_per_launch = float(np.mean(tagged_flops)) if tagged_flops else 0.0
+    durations = by_tag.get(1, [])
     mean_ms = float(np.mean(durations)) if durations else float('nan')
     achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12 if durations else float('nan')
+    # polling (tag 2 = canonical planes + poll kernel): the three figures SURVEY 8(d) asks for, from the same live events
+    polling = None
+    if by_tag.get(2):
+        poll_ms = float(np.mean(by_tag[2]))
+        n_pl, n_det = int(planes.shape[0]), 100
+        alg_bytes = B * (16.0 * n_pl + 13600.0)                            # plane DB tiled per image, as the reference feeds it
+        l2_bytes = B * n_det * n_pl * 16.0                                 # every detection streams the (L2-resident) database
+        poll_flops = 162.0 * B * n_det * n_pl
+        polling = {'launch_us': round(poll_ms * 1e3, 1), 'planes': n_pl,
+                   'algorithmic_GBps': round(alg_bytes / (poll_ms * 1e-3) / 1e9, 1),
+                   'frac_of_hbm_peak': round(alg_bytes / (poll_ms * 1e-3) / 8e12, 5),
+                   'l2_level_GBps': round(l2_bytes / (poll_ms * 1e-3) / 1e9, 1),
+                   'valu_tflops': round(poll_flops / (poll_ms * 1e-3) / 1e12, 2),
+                   'frac_of_fp32_vector_peak': round(poll_flops / (poll_ms * 1e-3) / 157.3e12, 4),
+                   'note': 'latency / VALU bound (exact IEEE divide + sqrt per pair), not HBM bound: the whole input is 16*N + 13600 bytes per image'}
     # HBM/fabric traffic of that kernel cannot be read live (PMC needs rocprofv3): report the committed
     # measurement of the same kernel on the same workload (profiles/r1/dominant_kernel_pmc.*, tools/pmc_bench.sh)
     traffic = None
@@ -231,7 +251,8 @@ def main():
                        'algorithmic_gflop_per_image': round(plan.flops / B / 1e9, 1),
                        'achieved_tflops_whole_path': round(plan.flops * args.steps / elapsed / 1e12, 1),
                        'host_fed_images_per_s_incl_pcie_and_gpu_preprocessing': pcie_rate,
-                       'host_fed_images_per_s_pipelined_uploads': pcie_pipelined, 'host_fed_detections': host_fed_detections},
+                       'host_fed_images_per_s_pipelined_uploads': pcie_pipelined, 'host_fed_detections': host_fed_detections,
+                       'polling_kernel': polling},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': traffic,
                          'traffic_unit': 'MB per launch at the L2<->fabric interface (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
