@@ -13,6 +13,7 @@
 // all 64 output channels of one pixel with the weights broadcast from scalar registers.
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "gpp.h"
@@ -88,13 +89,27 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
+// diagnostic build only (-DGPP_STAMPS): per-tile phase stamps of the first 64 workgroups (tools/stem_time.py)
+#ifdef GPP_STAMPS
+__device__ unsigned long long* g_stem_stamps = nullptr;
+#define STEM_STAMP(j)                                                                                     \
+    do {                                                                                                  \
+        if (g_stem_stamps && blockIdx.x < 64 && iter < 16 && tid == 0)                                    \
+            g_stem_stamps[(blockIdx.x * 16 + iter) * 8 + (j)] = __builtin_amdgcn_s_memrealtime();        \
+    } while (0)
+#else
+#define STEM_STAMP(j) do { } while (0)
+#endif
+
 constexpr int MW_PITCH = 232;                   // halfs per weight row in LDS (224 + 8: conflict-free b128 reads)
 constexpr int MP_PX = TW * 2 + 9;               // patch pixels per row: 2*63 + 32/3 rounded up
 constexpr int MP_PITCH = 416;                   // halfs per patch row (>= 3 * MP_PX = 411)
 constexpr int MP_ROWS = TH * 2 + 5;
 
 template <typename scalar, typename vec8>
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in, const _Float16* __restrict__ w,
+// (256, 2): without the second bound the compiler parks 96 values in AGPRs, 264 registers per lane in all, and only ONE
+// workgroup fits a CU -- the kernel then ran its 512 persistent workgroups as two rounds (80 us instead of 62)
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restrict__ in, const _Float16* __restrict__ w,
                                                         const float* __restrict__ bias, scalar* __restrict__ out,
                                                         int B, int H, int W, int Ho, int Wo)
 {
@@ -140,11 +155,15 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         }
     };
     if ((int)blockIdx.x < tiles) load_patch(blockIdx.x);
-    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    int iter = 0;
+    (void)iter;
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x, ++iter) {
         const int b = t / (tiles_x * tiles_y), r = t - b * (tiles_x * tiles_y);
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const int ox0 = tx * TW, oy0 = ty * TH;
+        STEM_STAMP(0);
         __syncthreads();                                     // previous tile's readers are done with s_p
+        STEM_STAMP(1);
 #pragma unroll
         for (int it = 0; it < PATCH_IT; ++it) {
             const int e = tid + it * 256;
@@ -152,7 +171,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             if (e < PATCH_PAIRS) *(f16x2*)(s_p + pr * MP_PITCH + c2) = (f16x2){(_Float16)patch[it][0], (_Float16)patch[it][1]};
         }
         __syncthreads();
+        STEM_STAMP(2);
         if (t + (int)gridDim.x < tiles) load_patch(t + gridDim.x);
+        STEM_STAMP(3);
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -175,6 +196,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
+        STEM_STAMP(4);
         const int oy = oy0 + wave;
         if (oy < Ho) {
 #pragma unroll
@@ -194,6 +216,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                 }
             }
         }
+        STEM_STAMP(5);
     }
 }
 
@@ -272,6 +295,13 @@ extern "C" int gpp_stem_conv7x7_bn_relu(const float* in, const float* weight, co
     return result();
 }
 
+#ifdef GPP_STAMPS
+extern "C" int gpp_debug_set_stem_stamps(void* buffer)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stem_stamps), &buffer, sizeof(buffer));
+}
+#endif
+
 extern "C" int gpp_stem_pack_weights_f16(const float* host_weight_147x64, void* host_packed, size_t packed_bytes)
 {
     // host-side helper: [147][64] float32 (HWIO flattened, BN scale folded) -> [64][232] f16, rows interleaved as for
@@ -298,7 +328,8 @@ extern "C" int gpp_stem_conv7x7_bn_relu_mfma(const float* in, const void* packed
     if (((uintptr_t)out | (uintptr_t)packed_weight_f16) & 15) return GPP_ERR_ALIGN;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     const int tiles = ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH) * B;
-    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);      // 2 workgroups / CU (register-limited), persistent
+    static const int per_cu = [] { const char* e = getenv("GPP_STEM_WGS_PER_CU"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    const unsigned grid = (unsigned)(tiles < 256 * per_cu ? tiles : 256 * per_cu);      // persistent workgroups
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GPP_BF16)
         stem_mfma_kernel<__bf16, bf16x8><<<grid, 256, 0, st>>>(in, (const _Float16*)packed_weight_f16, bias, (__bf16*)out, B, H, W, Ho, Wo);
