@@ -282,6 +282,46 @@ if __name__ == '__main__':
             hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(d), 16, hip.stream_ptr(), ctypes.byref(best)), 'autotune')
             print('%-28s -> tile %8d split %2d  %.1f us' % (name, d.tile_hint, d.split_k, best.value))
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'cold':
+        # how much of a small layer's in-network time is cold caches?  hot = back to back; cold = after a 1 GiB fill
+        # (L2 and Infinity Cache flushed); weights-warm = after the fill, the weights are read once (-> Infinity Cache);
+        # all-warm = after the fill, weights and input are read once
+        dev = torch.device('cuda')
+        flush = torch.empty((256 << 20,), dtype=torch.float32, device=dev)
+        for name, shp, cin, cout, k, tile, res in (('res5 2a 1x1 2048->512', [(13, 42)], 2048, 512, 1, 64128, False), ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3, 64128, False),
+                                                   ('res5 2c 1x1 512->2048 +res', [(13, 42)], 512, 2048, 1, 160128, True), ('res4 2a 1x1 1024->256', [(26, 84)], 1024, 256, 1, 96128, False),
+                                                   ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3, 96128, False), ('res4 2c 1x1 256->1024 +res', [(26, 84)], 256, 1024, 1, 64128, True),
+                                                   ('C5_reduced 1x1 2048->512', [(13, 42)], 2048, 512, 1, 64128, False), ('res3 2a 1x1 512->128', [(51, 167)], 512, 128, 1, 160128, False)):
+            tdt = C.torch_dtype('bf16')
+            h, wd = shp[0]
+            x = (torch.randn((B, h * wd, cin), device=dev) * 0.5).to(tdt)
+            o = torch.empty((B, h * wd, cout), device=dev, dtype=tdt)
+            r = (torch.randn((B, h * wd, cout), device=dev) * 0.5).to(tdt) if res else None
+            w = C.pack_weight((torch.randn((k, k, cin, cout)) * 0.02).numpy(), 'bf16', dev)
+            bias = torch.zeros((cout,), device=dev)
+            d = C.conv_desc([C.FMap(x, B, h, wd, cin)], [C.FMap(o, B, h, wd, cout)], w, bias, k, k, cin, cout, pad=(k // 2, k // 2), relu=True,
+                            dtype='bf16', tile_hint=tile, residuals=[C.FMap(r, B, h, wd, cout)] if res else None)
+            out = []
+            for mode in ('hot', 'cold', 'weights-warm', 'all-warm'):
+                ts = []
+                for it in range(8):
+                    if mode != 'hot':
+                        flush.fill_(float(it))
+                    if mode in ('weights-warm', 'all-warm'):
+                        w.view(torch.int16).sum()
+                    if mode == 'all-warm':
+                        x.view(torch.int16).sum()
+                        if res:
+                            r.view(torch.int16).sum()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    C.run_conv(d)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) * 1e3)
+                out.append('%s %.1f' % (mode, sorted(ts)[len(ts) // 2]))
+            print('%-30s tile %7d   us (median of 8, single launches): %s' % (name, tile, '   '.join(out)))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'big':
         for rep in range(2):
             for tile in (512, 128):
