@@ -1,0 +1,33 @@
+""" The driver's contract for bench.py: one JSON line with the agreed keys (run as a child process, like the driver does). """
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--cpu-images', '1'],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in rec, key
+    assert rec['n_gpus'] == 1 and rec['steps'] == 3 and rec['warmup'] == 1 and rec['unit'] == 'images/s' and rec['vs_baseline'] is None
+    assert rec['higher_is_better'] is True and rec['scaling'] == 'weak' and rec['dtype'] == 'bf16' and rec['data'] == 'synthetic'
+    assert 'workload' in rec['config'] and 'model' not in rec['config']
+    assert abs(rec['value'] - 8 * 3 / (rec['ms_per_step'] * 3e-3)) < 0.01 * rec['value']
+    roof = rec['roofline']
+    assert roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    assert 0.2 < roof['frac'] < 1.0 and roof['launches_timed'] == 9                 # 3 regression-tower launches x 3 steps
+    cpu = rec['cpu_baseline']
+    assert cpu['kind'] == 'port' and cpu['cores'] >= 1 and cpu['value'] > 0 and 'sample' in cpu
+    poll = rec['config']['polling_kernel']
+    assert poll['planes'] == 1000 and poll['launch_us'] > 0 and 0 < poll['frac_of_hbm_peak'] < 0.01
