@@ -100,6 +100,37 @@ __global__ __launch_bounds__(256) void candidates_kernel(const float* __restrict
     }
 }
 
+// orientation_specific_filter=True (filter_detections.py:84-98): one candidate list per (image, orientation), keyed by that
+// orientation's folded score max(s[o], s[o + 4]); an anchor can enter up to four lists.  Counter / key list / header slot
+// of list (b, o) = 4 * b + o.
+__global__ __launch_bounds__(256) void candidates_osf_kernel(const float* __restrict__ cls, int64_t n_anchors, int64_t key_stride,
+                                                             float thr, unsigned long long* __restrict__ keys,
+                                                             int32_t* __restrict__ counts)
+{
+    const int b = blockIdx.y;
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= n_anchors) return;
+    const float4* src = (const float4*)(cls + ((int64_t)b * n_anchors + a) * 8);
+    const float4 v0 = src[0], v1 = src[1];
+    const float l[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const float lmax = fmaxf(fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3])), fmaxf(fmaxf(l[4], l[5]), fmaxf(l[6], l[7])));
+    if (thr >= 0.048f && lmax < -3.0f) return;               // the same exact rejects as candidates_kernel: no orientation can pass
+    if (sigmoidf(lmax) < thr - 1e-5f) return;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = sigmoidf(l[k]);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const float so = fmaxf(s[o], s[o + 4]);
+        if (so > thr) {
+            const int list = 4 * b + o;
+            const int slot = atomicAdd(&counts[list * (kCounterStride / 4)], 1);
+            keys[(int64_t)list * key_stride + slot] =
+                ((unsigned long long)__float_as_uint(so) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)a);
+        }
+    }
+}
+
 __constant__ float kBoxMean[12] = {-0.0373f, -0.0165f, 0.0373f, 0.0171f, -0.0286f, -0.0478f,
                                    0.2929f, 0.0114f, 0.0288f, -0.0589f, 0.2932f, -0.0007f};   // _misc.py:115
 __constant__ float kBoxStd[12] = {0.1957f, 0.1896f, 0.1957f, 0.1897f, 0.1967f, 0.2034f,
@@ -302,7 +333,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(
     const float* __restrict__ cls, const float* __restrict__ reg, const float* __restrict__ regdim,
     const float4* __restrict__ anchors, int64_t n_anchors, Layout L, float iou_thr, int max_det,
     int32_t* __restrict__ o_counts, float4* __restrict__ ws_boxes, unsigned char* __restrict__ ws_alive,
-    unsigned char* __restrict__ header)
+    unsigned char* __restrict__ header, int lists_per_image)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
     unsigned long long* lkeys = (unsigned long long*)nms_smem;                 // kLdsKeys keys while sorting ...
@@ -310,12 +341,14 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(
     int* hist = (int*)(nms_smem + (size_t)kLdsKeys * 16);                      // kHistBins counters
     __shared__ NmsShared sh;
 
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int K = min(counts[b * (kCounterStride / 4)], (int)n_anchors);
-    if (o_counts && tid == 0) o_counts[b] = K;
-    unsigned long long* gkeys = keys + (int64_t)b * key_stride;
-    float4* boxes4 = ws_boxes + (int64_t)b * n_anchors;
-    unsigned char* alive = ws_alive + (int64_t)b * n_anchors;
+    // one workgroup per candidate list: list = image (default) or 4 * image + orientation (orientation_specific_filter)
+    const int list = blockIdx.x, tid = threadIdx.x;
+    const int b = list / lists_per_image;
+    const int K = min(counts[list * (kCounterStride / 4)], (int)n_anchors);
+    if (o_counts && tid == 0 && lists_per_image == 1) o_counts[b] = K;
+    unsigned long long* gkeys = keys + (int64_t)list * key_stride;
+    float4* boxes4 = ws_boxes + (int64_t)list * n_anchors;
+    unsigned char* alive = ws_alive + (int64_t)list * n_anchors;
 
     // corners x1 y1 x2 y2 of the first `cnt` sorted candidates (filter_detections.py:58,61 uses boxes[:, :4])
     auto prepare = [&](const unsigned long long* sk, int cnt) {
@@ -447,7 +480,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(
 
     // ---- hand-over to emit_kernel: the keys of the survivors, in score order, next to this image's counter
     __syncthreads();
-    unsigned char* slot = header + (int64_t)b * kCounterStride;
+    unsigned char* slot = header + (int64_t)list * kCounterStride;
     if (tid == 0) ((int32_t*)slot)[kKeptCountWord] = kept;
     for (int t = tid; t < kept; t += kNmsThreads) ((unsigned long long*)(slot + kKeptKeysOffset))[t] = sk[sh.kept[t]];
 }
@@ -500,6 +533,82 @@ __global__ __launch_bounds__(128) void emit_kernel(
     }
 }
 
+// orientation_specific_filter: the four survivor lists of an image (each in score order) are concatenated in orientation
+// order and tf.nn.top_k picks max_det of them: descending score, earlier position first on ties (filter_detections.py:152-167).
+// Rank by counting; the orientation of an entry is the list it came from, its score is the key's.
+__global__ __launch_bounds__(512) void emit_osf_kernel(
+    const unsigned char* __restrict__ header, const float* __restrict__ cls, const float* __restrict__ reg,
+    const float* __restrict__ regdim, const float4* __restrict__ anchors, int64_t n_anchors, Layout L, int max_det,
+    float* __restrict__ o_boxes, float* __restrict__ o_dims, float* __restrict__ o_scores,
+    int32_t* __restrict__ o_labels, int32_t* __restrict__ o_orient, int32_t* __restrict__ o_anchor, int32_t* __restrict__ o_counts)
+{
+    __shared__ unsigned long long s_key[512];
+    __shared__ int s_total;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int cnt[4], off[5];
+    off[0] = 0;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        cnt[o] = ((const int32_t*)(header + (int64_t)(4 * b + o) * kCounterStride))[kKeptCountWord];
+        off[o + 1] = off[o] + cnt[o];
+    }
+    const int total = off[4];                                   // <= 4 * 128
+    int my_o = -1;
+    unsigned long long my_key = 0ull;
+    if (tid < total) {
+        my_o = (tid >= off[3]) ? 3 : (tid >= off[2]) ? 2 : (tid >= off[1]) ? 1 : 0;
+        my_key = ((const unsigned long long*)(header + (int64_t)(4 * b + my_o) * kCounterStride + kKeptKeysOffset))[tid - off[my_o]];
+    }
+    s_key[tid] = my_key;
+    if (tid == 0) {
+        s_total = total;
+        if (o_counts) {                                         // candidates of the image = sum over its four lists
+            int c = 0;
+            for (int o = 0; o < 4; ++o) c += ((const int32_t*)(header + (int64_t)(4 * b + o) * kCounterStride))[0];
+            o_counts[b] = c;
+        }
+    }
+    __syncthreads();
+    if (tid < total) {
+        const uint32_t mine = (uint32_t)(my_key >> 32);
+        int rank = 0;
+        for (int q = 0; q < total; ++q) {
+            const uint32_t other = (uint32_t)(s_key[q] >> 32);  // positive floats: the bit patterns order like the values
+            rank += (other > mine || (other == mine && q < tid)) ? 1 : 0;
+        }
+        if (rank < max_det) {
+            const int64_t row = (int64_t)b * max_det + rank;
+            const int64_t a = (int64_t)(0xFFFFFFFFu - (uint32_t)(my_key & 0xFFFFFFFFull));
+            const float4* src = (const float4*)(cls + ((int64_t)b * n_anchors + a) * 8);
+            const float4 v0 = src[0], v1 = src[1];
+            const float l[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const Folded f = fold8(l);                          // only its sign is used: RegressBoxes does not know the list
+            const float4 an = anchors[a];
+            float* ob = o_boxes + row * 12;
+            float* od = o_dims + row * 3;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) ob[j] = box_coord(j, an, reg_at(reg, L, n_anchors, b, a, j), f.sign);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) od[j] = regdim[((int64_t)b * n_anchors + a) * 3 + j] * kDimStd[j] + kDimMean[j];
+            o_scores[row] = __uint_as_float(mine);
+            o_labels[row] = 0;
+            o_orient[row] = my_o;
+            if (o_anchor) o_anchor[row] = (int32_t)a;
+        }
+    }
+    for (int t = min(total, max_det) + tid; t < max_det; t += 512) {
+        const int64_t row = (int64_t)b * max_det + t;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) o_boxes[row * 12 + j] = -1.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o_dims[row * 3 + j] = -1.0f;
+        o_scores[row] = -1.0f;
+        o_labels[row] = -1;
+        o_orient[row] = -1;
+        if (o_anchor) o_anchor[row] = -1;
+    }
+}
+
 inline int64_t pow2_ceil(int64_t v)
 {
     int64_t n = 1;
@@ -509,13 +618,88 @@ inline int64_t pow2_ceil(int64_t v)
 
 }  // namespace
 
-extern "C" int gpp_detect_workspace_bytes(int B, int64_t n_anchors, size_t* bytes)
+namespace {
+
+size_t detect_bytes(int B, int64_t n_anchors, int lists_per_image)
 {
-    if (!bytes || B < 0 || n_anchors <= 0) return GPP_ERR_BAD_ARG;
     const size_t keys = (size_t)pow2_ceil(n_anchors) * 8;
     const size_t boxes = (size_t)n_anchors * 16;
     const size_t alive = ((size_t)n_anchors + 15) / 16 * 16;
-    *bytes = kHeaderBytes + (size_t)B * (keys + boxes + alive);
+    return kHeaderBytes + (size_t)B * lists_per_image * (keys + boxes + alive);
+}
+
+int detect_impl(int stages, int lists_per_image, const float* cls_logits, const float* regression, const float* regression_dim,
+                const float* anchors, int B, int64_t n_anchors, int num_base_anchors, int fused_layout, float score_thr,
+                float iou_thr, int max_det, float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
+                int32_t* anchor_index, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (stages <= 0 || stages > 7) return GPP_ERR_BAD_ARG;
+    if (B < 0 || n_anchors <= 0 || max_det <= 0 || max_det > 128 || num_base_anchors <= 0) return GPP_ERR_BAD_ARG;
+    if (n_anchors >= (1LL << 31) || n_anchors % num_base_anchors != 0) return GPP_ERR_UNSUPPORTED;
+    if (B == 0) return GPP_OK;
+    if (!cls_logits || !regression || !regression_dim || !anchors || !boxes || !dims || !scores || !labels ||
+        !orientations || !workspace)
+        return GPP_ERR_BAD_ARG;
+    if (((uintptr_t)cls_logits | (uintptr_t)anchors | (uintptr_t)workspace) & 15) return GPP_ERR_ALIGN;
+    if (workspace_bytes < detect_bytes(B, n_anchors, lists_per_image)) return GPP_ERR_WORKSPACE;
+    const int lists = B * lists_per_image;
+    if (lists > 64) return GPP_ERR_UNSUPPORTED;            // header slots
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    // per-list candidate counters, one per kCounterStride bytes: adjacent counters share an L2 channel and
+    // their returning atomics serialise (measured: 66 us for 8 x 800 candidates on one cache line)
+    int32_t* cnt = (int32_t*)ws;
+    const int64_t kstride = pow2_ceil(n_anchors);
+    unsigned long long* keys = (unsigned long long*)(ws + kHeaderBytes);
+    float4* wboxes = (float4*)(ws + kHeaderBytes + (size_t)lists * kstride * 8);
+    unsigned char* alive = (unsigned char*)(wboxes + (size_t)lists * n_anchors);
+    Layout L = {fused_layout, num_base_anchors};
+    const bool osf = lists_per_image == 4;
+    hipError_t e;
+    if (stages & GPP_DETECT_CANDIDATES) {                  // needs cls_logits only
+        e = hipMemsetAsync(cnt, 0, (size_t)lists * kCounterStride, st);      // the header slots of this call's lists
+        if (e != hipSuccess) return (int)e;
+        const dim3 grid((unsigned)((n_anchors + 255) / 256), (unsigned)B);
+        if (osf) candidates_osf_kernel<<<grid, 256, 0, st>>>(cls_logits, n_anchors, kstride, score_thr, keys, cnt);
+        else candidates_kernel<<<grid, 256, 0, st>>>(cls_logits, n_anchors, kstride, score_thr, keys, cnt);
+    }
+    if (stages & GPP_DETECT_SELECT) {                      // needs the candidates and the corner regressions
+        static bool configured = false;
+        if (!configured) {
+            e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsKeys * 16 + kHistBins * 4);
+            if (e != hipSuccess) return (int)e;
+            configured = true;
+        }
+        nms_kernel<<<dim3((unsigned)lists), kNmsThreads, kLdsKeys * 16 + kHistBins * 4, st>>>(
+            keys, cnt, kstride, cls_logits, regression, regression_dim, (const float4*)anchors, n_anchors, L, iou_thr, max_det,
+            counts, wboxes, alive, ws, lists_per_image);
+    }
+    if (stages & GPP_DETECT_EMIT) {                        // needs every head tensor
+        if (osf)
+            emit_osf_kernel<<<dim3((unsigned)B), 512, 0, st>>>(ws, cls_logits, regression, regression_dim, (const float4*)anchors,
+                                                               n_anchors, L, max_det, boxes, dims, scores, labels, orientations,
+                                                               anchor_index, counts);
+        else
+            emit_kernel<<<dim3((unsigned)B), 128, 0, st>>>(ws, cls_logits, regression, regression_dim, (const float4*)anchors,
+                                                           n_anchors, L, max_det, boxes, dims, scores, labels, orientations, anchor_index);
+    }
+    e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" int gpp_detect_workspace_bytes(int B, int64_t n_anchors, size_t* bytes)
+{
+    if (!bytes || B < 0 || n_anchors <= 0) return GPP_ERR_BAD_ARG;
+    *bytes = detect_bytes(B, n_anchors, 1);
+    return GPP_OK;
+}
+
+extern "C" int gpp_detect_osf_workspace_bytes(int B, int64_t n_anchors, size_t* bytes)
+{
+    if (!bytes || B < 0 || n_anchors <= 0) return GPP_ERR_BAD_ARG;
+    *bytes = detect_bytes(B, n_anchors, 4);
     return GPP_OK;
 }
 
@@ -526,51 +710,20 @@ extern "C" int gpp_detect_stages_f32(int stages, const float* cls_logits, const 
                                      int32_t* anchor_index, int32_t* counts,
                                      void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (stages <= 0 || stages > 7) return GPP_ERR_BAD_ARG;
-    if (B < 0 || n_anchors <= 0 || max_det <= 0 || max_det > 128 || num_base_anchors <= 0) return GPP_ERR_BAD_ARG;
-    if (n_anchors >= (1LL << 31) || n_anchors % num_base_anchors != 0) return GPP_ERR_UNSUPPORTED;
-    if (B == 0) return GPP_OK;
-    if (!cls_logits || !regression || !regression_dim || !anchors || !boxes || !dims || !scores || !labels ||
-        !orientations || !workspace)
-        return GPP_ERR_BAD_ARG;
-    if (((uintptr_t)cls_logits | (uintptr_t)anchors | (uintptr_t)workspace) & 15) return GPP_ERR_ALIGN;
-    size_t need = 0;
-    gpp_detect_workspace_bytes(B, n_anchors, &need);
-    if (workspace_bytes < need) return GPP_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned char* ws = (unsigned char*)workspace;
-    // per-image candidate counters, one per kCounterStride bytes: adjacent counters share an L2 channel and
-    // their returning atomics serialise (measured: 66 us for 8 x 800 candidates on one cache line)
-    int32_t* cnt = (int32_t*)ws;
-    if (B > 64) return GPP_ERR_UNSUPPORTED;
-    const int64_t kstride = pow2_ceil(n_anchors);
-    unsigned long long* keys = (unsigned long long*)(ws + kHeaderBytes);
-    float4* wboxes = (float4*)(ws + kHeaderBytes + (size_t)B * kstride * 8);
-    unsigned char* alive = (unsigned char*)(wboxes + (size_t)B * n_anchors);
-    Layout L = {fused_layout, num_base_anchors};
-    hipError_t e;
-    if (stages & GPP_DETECT_CANDIDATES) {                  // needs cls_logits only
-        e = hipMemsetAsync(cnt, 0, (size_t)B * kCounterStride, st);      // the header slots of the B images of this call
-        if (e != hipSuccess) return (int)e;
-        candidates_kernel<<<dim3((unsigned)((n_anchors + 255) / 256), (unsigned)B), 256, 0, st>>>(
-            cls_logits, n_anchors, kstride, score_thr, keys, cnt);
-    }
-    if (stages & GPP_DETECT_SELECT) {                      // needs the candidates and the corner regressions
-        static bool configured = false;
-        if (!configured) {
-            e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsKeys * 16 + kHistBins * 4);
-            if (e != hipSuccess) return (int)e;
-            configured = true;
-        }
-        nms_kernel<<<dim3((unsigned)B), kNmsThreads, kLdsKeys * 16 + kHistBins * 4, st>>>(
-            keys, cnt, kstride, cls_logits, regression, regression_dim, (const float4*)anchors, n_anchors, L, iou_thr, max_det,
-            counts, wboxes, alive, ws);
-    }
-    if (stages & GPP_DETECT_EMIT)                          // needs every head tensor
-        emit_kernel<<<dim3((unsigned)B), 128, 0, st>>>(ws, cls_logits, regression, regression_dim, (const float4*)anchors, n_anchors,
-                                                       L, max_det, boxes, dims, scores, labels, orientations, anchor_index);
-    e = hipGetLastError();
-    return e == hipSuccess ? GPP_OK : (int)e;
+    return detect_impl(stages, 1, cls_logits, regression, regression_dim, anchors, B, n_anchors, num_base_anchors, fused_layout, score_thr,
+                       iou_thr, max_det, boxes, dims, scores, labels, orientations, anchor_index, counts, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gpp_detect_osf_f32(const float* cls_logits, const float* regression, const float* regression_dim,
+                                  const float* anchors, int B, int64_t n_anchors, int num_base_anchors, int fused_layout,
+                                  float score_thr, float iou_thr, int max_det,
+                                  float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
+                                  int32_t* anchor_index, int32_t* counts,
+                                  void* workspace, size_t workspace_bytes, void* stream)
+{
+    return detect_impl(GPP_DETECT_CANDIDATES | GPP_DETECT_SELECT | GPP_DETECT_EMIT, 4, cls_logits, regression, regression_dim, anchors, B,
+                       n_anchors, num_base_anchors, fused_layout, score_thr, iou_thr, max_det, boxes, dims, scores, labels, orientations,
+                       anchor_index, counts, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gpp_detect_f32(const float* cls_logits, const float* regression, const float* regression_dim,

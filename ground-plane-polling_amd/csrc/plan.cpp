@@ -114,6 +114,14 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
                                 d->workspace_bytes, stream);
             break;
         }
+        case GPP_OP_DETECT_OSF: {
+            const gpp_detect_desc* d = (const gpp_detect_desc*)op.desc;
+            rc = gpp_detect_osf_f32(d->cls_logits, d->regression, d->regression_dim, d->anchors, d->B, d->n_anchors,
+                                    d->num_base_anchors, d->fused_layout, d->score_thr, d->iou_thr, d->max_det, d->boxes, d->dims,
+                                    d->scores, d->labels, d->orientations, d->anchor_index, d->counts, d->workspace,
+                                    d->workspace_bytes, stream);
+            break;
+        }
         case GPP_OP_DETECT_CANDIDATES:
         case GPP_OP_DETECT_SELECT:
         case GPP_OP_DETECT_EMIT: {

@@ -94,6 +94,10 @@ def _declare(lib):
     lib.gpp_detect_f32.restype = c_int
     lib.gpp_detect_f32.argtypes = [c_void_p] * 4 + [c_int, c_int64, c_int, c_int, c_float, c_float, c_int] + \
         [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]
+    lib.gpp_detect_osf_workspace_bytes.restype = c_int
+    lib.gpp_detect_osf_workspace_bytes.argtypes = lib.gpp_detect_workspace_bytes.argtypes
+    lib.gpp_detect_osf_f32.restype = c_int
+    lib.gpp_detect_osf_f32.argtypes = lib.gpp_detect_f32.argtypes
     lib.gpp_detect_stages_f32.restype = c_int
     lib.gpp_detect_stages_f32.argtypes = [c_int] + lib.gpp_detect_f32.argtypes
     lib.gpp_conv2d_flops.restype = c_int

@@ -7,7 +7,7 @@ read exactly once and only the 100 padded detections per image are written:
     RegressDims        /root/reference/keras_retinanet_3D/layers/_misc.py:156-199
     FilterDetections   /root/reference/keras_retinanet_3D/layers/filter_detections.py:192-304
 (plus the sigmoid of models/retinanet.py:72-73).  Implemented: nms=True|False, class_specific_filter=True|False (identical for one class),
-orientation_specific_filter=False, one object class (the reference's only trained case, preprocessing/kitti.py:28-35).
+orientation_specific_filter=False|True, one object class (the reference's only trained case, preprocessing/kitti.py:28-35).
 """
 
 import numpy as np
@@ -27,9 +27,9 @@ class FilterDetections(object):
                  nms_threshold=NMS_THRESHOLD, score_threshold=SCORE_THRESHOLD, max_detections=MAX_DETECTIONS,
                  fused_regression=False):
         import torch
-        if orientation_specific_filter:
-            raise NotImplementedError('orientation_specific_filter=True is not implemented on the device '
-                                      '(models.load_model / convert_model.py default to False)')
+        self.osf = bool(orientation_specific_filter)     # per-orientation threshold + NMS (filter_detections.py:84-98)
+        if self.osf and int(batch) > 16:
+            raise ValueError('orientation_specific_filter=True handles at most 16 images per call')
         if not nms:
             nms_threshold = 2.0      # IoU never exceeds 1: nothing is suppressed, the kernel reduces to threshold + top-k
         self.batch, self.n_anchors, self.device = int(batch), int(n_anchors), device
@@ -45,7 +45,8 @@ class FilterDetections(object):
         self.anchor_index = torch.empty((B, D), dtype=i32, device=device)
         self.counts = torch.zeros((max(B, 1),), dtype=i32, device=device)
         need = hip.c_size_t(0)
-        hip.check(hip.lib().gpp_detect_workspace_bytes(B, self.n_anchors, need), 'gpp_detect_workspace_bytes')
+        size_fn = hip.lib().gpp_detect_osf_workspace_bytes if self.osf else hip.lib().gpp_detect_workspace_bytes
+        hip.check(size_fn(B, self.n_anchors, need), 'gpp_detect_workspace_bytes')
         self.workspace = torch.empty((int(need.value),), dtype=torch.uint8, device=device)
 
     def args(self, cls_logits, regression, regression_dim, anchors):
@@ -61,8 +62,8 @@ class FilterDetections(object):
         anchors (A, 4): float32 device tensors.  Returns [boxes, dimensions, scores, labels, orientations]
         in the reference's output order (filter_detections.py:189). """
         if self.batch > 0:
-            hip.check(hip.lib().gpp_detect_f32(*(self.args(cls_logits, regression, regression_dim, anchors) + (hip.stream_ptr(),))),
-                      'gpp_detect_f32')
+            fn = hip.lib().gpp_detect_osf_f32 if self.osf else hip.lib().gpp_detect_f32
+            hip.check(fn(*(self.args(cls_logits, regression, regression_dim, anchors) + (hip.stream_ptr(),))), 'gpp_detect_f32')
         return [self.boxes, self.dimensions, self.scores, self.labels, self.orientations]
 
 

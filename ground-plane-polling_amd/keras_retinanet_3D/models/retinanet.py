@@ -84,7 +84,8 @@ class TailNextDesc(ctypes.Structure):
 OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4, 5, 6, 7
 OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT = 8, 9, 10
 OP_TAIL_NEXT = 11
-DETECT_OPS = (OP_DETECT, OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT)
+OP_DETECT_OSF = 12
+DETECT_OPS = (OP_DETECT, OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT, 12)
 OP_JOIN, OP_SYNC = 0x10000, 0x20000
 
 
@@ -119,9 +120,7 @@ class RetinaNet3D(object):
     def __init__(self, weights, backbone_name='resnet50', dtype='bf16', nms=True, class_specific_filter=True,
                  orientation_specific_filter=False, name='retinanet-bbox'):
         import torch
-        if orientation_specific_filter:
-            raise NotImplementedError('the device decode implements orientation_specific_filter=False '
-                                      '(what models.load_model produces by default)')
+        self.osf = bool(orientation_specific_filter)     # per-orientation NMS (filter_detections.py:84-98), gpp_detect_osf_f32
         self.nms = bool(nms)
         self.name = name
         self.backbone_name = backbone_name.split('_')[0]
@@ -372,7 +371,7 @@ class RetinaNet3D(object):
         # The detection selection (threshold + sort + greedy NMS: one workgroup per image, latency-bound, 8 of the
         # 256 CUs) only needs the classification logits and the corner regressions, so it runs on a side stream
         # underneath the dimension tower; the full decode of the <= 100 survivors joins when every head is done.
-        overlap = os.environ.get('GPP_DECODE_OVERLAP', '1') != '0' and not head_lanes
+        overlap = os.environ.get('GPP_DECODE_OVERLAP', '1') != '0' and not head_lanes and not self.osf
         plan.decode_overlap = overlap
 
         def dim_tower():
@@ -413,7 +412,10 @@ class RetinaNet3D(object):
         plan.anchor_index = torch.empty((B, D), dtype=i32, device=dev)
         plan.counts = torch.zeros((B,), dtype=i32, device=dev)
         need = hip.c_size_t(0)
-        hip.check(hip.lib().gpp_detect_workspace_bytes(B, plan.n_anchors, need), 'gpp_detect_workspace_bytes')
+        if self.osf and B > 16:
+            raise ValueError('orientation_specific_filter=True handles at most 16 images per batch')
+        size_fn = hip.lib().gpp_detect_osf_workspace_bytes if self.osf else hip.lib().gpp_detect_workspace_bytes
+        hip.check(size_fn(B, plan.n_anchors, need), 'gpp_detect_workspace_bytes')
         plan.detect_ws = torch.empty((int(need.value),), dtype=torch.uint8, device=dev)
         anchors = self._anchor_table((H, Wd))
         dd = DetectDesc(plan.cls_logits.data_ptr(), plan.regression.data_ptr(), plan.regression_dim.data_ptr(),
@@ -431,7 +433,7 @@ class RetinaNet3D(object):
             plan.lanes.insert(at, 1 << 8)
             plan.add(OP_DETECT_EMIT, dd, 'filtered_detections', join=True)
         else:
-            plan.add(OP_DETECT, dd, 'filtered_detections', join=True)
+            plan.add(OP_DETECT_OSF if self.osf else OP_DETECT, dd, 'filtered_detections', join=True)
 
         # ---- ground-plane polling (FitRoadPlanes)
         plan.keypoints = torch.empty((B, D, 4, 3), dtype=f32, device=dev)

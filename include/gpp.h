@@ -254,6 +254,18 @@ int gpp_detect_stages_f32(int stages, const float* cls_logits, const float* regr
                           int32_t* anchor_index, int32_t* counts,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* orientation_specific_filter=True (layers/filter_detections.py:84-98, a non-default argument of models.load_model): threshold
+ * and NMS once per orientation on that orientation's folded score, the four survivor lists concatenated in orientation
+ * order, then the common top-k; an anchor may be reported once per orientation.  Same arguments as gpp_detect_f32; its own
+ * (4x larger) workspace; at most 16 images per call. */
+int gpp_detect_osf_workspace_bytes(int B, int64_t n_anchors, size_t* bytes);
+int gpp_detect_osf_f32(const float* cls_logits, const float* regression, const float* regression_dim,
+                       const float* anchors, int B, int64_t n_anchors, int num_base_anchors, int fused_layout,
+                       float score_thr, float iou_thr, int max_det,
+                       float* boxes, float* dims, float* scores, int32_t* labels, int32_t* orientations,
+                       int32_t* anchor_index, int32_t* counts,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Plan execution: one call enqueues a whole predict_on_batch (every kernel of the graph that
  * models/retinanet.py:359-422 `retinanet_bbox` builds) from a host array of descriptors.
@@ -273,6 +285,7 @@ int gpp_detect_stages_f32(int stages, const float* cls_logits, const float* regr
 #define GPP_OP_DETECT_SELECT 9
 #define GPP_OP_DETECT_EMIT 10
 #define GPP_OP_BOTTLENECK_TAIL_NEXT 11   /* gpp_tail_next_desc */
+#define GPP_OP_DETECT_OSF 12             /* gpp_detect_desc -> gpp_detect_osf_f32 */
 /* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
    that forks from the caller's stream at the first op of that lane; `kind | GPP_OP_JOIN` on a lane-0 op makes it wait
    for every open lane (the end of the plan joins too).  The caller orders the ops so that each lane only depends on

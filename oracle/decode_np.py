@@ -169,13 +169,47 @@ def fold_classification(classification):
     return folded.max(axis=1), np.argmax(folded, axis=1)
 
 
-def filter_detections(boxes, dimensions, classification, score_threshold=0.05, max_detections=100, nms_threshold=0.5, nms=True):
+def filter_detections(boxes, dimensions, classification, score_threshold=0.05, max_detections=100, nms_threshold=0.5, nms=True,
+                      orientation_specific_filter=False):
     """ One image.  boxes (A, 12), dimensions (A, 3), classification (A, 8) sigmoid scores ->
     [boxes (100, 12), dimensions (100, 3), scores (100,), labels (100,) i32, orientations (100,) i32],
-    padded with -1, plus the selected anchor indices (for tests). """
+    padded with -1, plus the selected anchor indices (for tests).
+    orientation_specific_filter (filter_detections.py:84-98): threshold + NMS once per orientation on that orientation's
+    folded score, the four survivor lists concatenated in orientation order, then the common top-k; an anchor can appear
+    once per orientation. """
     boxes = np.asarray(boxes, dtype=F)
     dimensions = np.asarray(dimensions, dtype=F)
     scores_all, orient_all = fold_classification(classification)
+    if orientation_specific_filter:
+        c = np.asarray(classification, dtype=F)
+        folded = np.maximum(c[:, :4], c[:, 4:])                  # folded[:, o] = classification_all[o::4, 0]
+        idx_parts, or_parts = [], []
+        for o in range(4):
+            so = folded[:, o]
+            io = np.nonzero(so > F(score_threshold))[0]
+            if nms:
+                io = io[non_max_suppression(boxes[io, :4], so[io], max_detections, nms_threshold)]
+            idx_parts.append(io)
+            or_parts.append(np.full((len(io),), o, dtype=np.int64))
+        idx = np.concatenate(idx_parts)
+        orient_sel = np.concatenate(or_parts)
+        sc = folded[idx, orient_sel]
+        order = np.argsort(-sc, kind='stable')[:max_detections]  # tf.nn.top_k over the concatenation
+        idx, orient_sel, sc = idx[order], orient_sel[order], sc[order]
+        n = len(idx)
+        out_boxes = -np.ones((max_detections, 12), dtype=F)
+        out_dims = -np.ones((max_detections, 3), dtype=F)
+        out_scores = -np.ones((max_detections,), dtype=F)
+        out_labels = -np.ones((max_detections,), dtype=np.int32)
+        out_orient = -np.ones((max_detections,), dtype=np.int32)
+        out_boxes[:n] = boxes[idx]
+        out_dims[:n] = dimensions[idx]
+        out_scores[:n] = sc
+        out_labels[:n] = 0
+        out_orient[:n] = orient_sel
+        anchor_idx = -np.ones((max_detections,), dtype=np.int64)
+        anchor_idx[:n] = idx
+        return [out_boxes, out_dims, out_scores, out_labels, out_orient], anchor_idx
     idx = np.nonzero(scores_all > F(score_threshold))[0]
     if nms:                                                      # filter_detections.py:56-64
         keep = non_max_suppression(boxes[idx, :4], scores_all[idx], max_detections, nms_threshold)
@@ -199,7 +233,7 @@ def filter_detections(boxes, dimensions, classification, score_threshold=0.05, m
     return [out_boxes, out_dims, out_scores, out_labels, out_orient], anchor_idx
 
 
-def detect(cls_logits, regression, regression_dim, anchors):
+def detect(cls_logits, regression, regression_dim, anchors, **filter_kwargs):
     """ Whole decode for a batch: logits (B, A, 8), regression (B, A, 12), regression_dim (B, A, 3),
     anchors (A, 4) -> the five padded tensors of filter_detections, batched, + anchor indices. """
     cls = sigmoid(cls_logits)
@@ -208,7 +242,7 @@ def detect(cls_logits, regression, regression_dim, anchors):
     dims = regress_dims(regression_dim)
     outs, aidx = [], []
     for b in range(B):
-        o, a = filter_detections(boxes[b], dims[b], cls[b])
+        o, a = filter_detections(boxes[b], dims[b], cls[b], **filter_kwargs)
         outs.append(o)
         aidx.append(a)
     return [np.stack([o[k] for o in outs]) for k in range(5)], np.stack(aidx)

@@ -60,12 +60,20 @@ def make_case(image_hw, batch, seed, logit_mean, logit_std):
     det = [np.stack([np.asarray(o[k]) for o in outs]) for k in range(5)]
     outs2 = [ref_filter(boxes[b], dims[b], cls[b], nms=False) for b in range(batch)]          # load_model(..., nms=False)
     det2 = [np.stack([np.asarray(o[k]) for o in outs2]) for k in range(5)]
+    outs3 = [ref_filter(boxes[b], dims[b], cls[b], orientation_specific_filter=True) for b in range(batch)]
+    det3 = [np.stack([np.asarray(o[k]) for o in outs3]) for k in range(5)]
+    outs4 = [ref_filter(boxes[b], dims[b], cls[b], orientation_specific_filter=True, nms=False) for b in range(batch)]
+    det4 = [np.stack([np.asarray(o[k]) for o in outs4]) for k in range(5)]
     return dict(image_hw=np.array(image_hw), anchors=anchors[0], logits=logits, classification=cls, regression=regression,
                 regression_dim=regression_dim, all_boxes=boxes.astype(F), all_dims=dims.astype(F),
                 boxes=det[0].astype(F), dimensions=det[1].astype(F), scores=det[2].astype(F),
                 labels=det[3].astype(np.int32), orientations=det[4].astype(np.int32),
                 nonms_boxes=det2[0].astype(F), nonms_dimensions=det2[1].astype(F), nonms_scores=det2[2].astype(F),
-                nonms_labels=det2[3].astype(np.int32), nonms_orientations=det2[4].astype(np.int32))
+                nonms_labels=det2[3].astype(np.int32), nonms_orientations=det2[4].astype(np.int32),
+                osf_boxes=det3[0].astype(F), osf_dimensions=det3[1].astype(F), osf_scores=det3[2].astype(F),
+                osf_labels=det3[3].astype(np.int32), osf_orientations=det3[4].astype(np.int32),
+                osfnonms_boxes=det4[0].astype(F), osfnonms_dimensions=det4[1].astype(F), osfnonms_scores=det4[2].astype(F),
+                osfnonms_labels=det4[3].astype(np.int32), osfnonms_orientations=det4[4].astype(np.int32))
 
 
 def main():

@@ -156,3 +156,38 @@ def test_stages_enqueued_separately_equal_the_single_call():
     for g_, w_ in zip(got, want):
         assert helpers.bits_equal(g_, w_)
     assert hip.lib().gpp_detect_stages_f32(0, *args) == -1 and hip.lib().gpp_detect_stages_f32(8, *args) == -1
+
+
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('name', CASES)
+def test_orientation_specific_filter_matches_reference_goldens(name, fused):
+    """ orientation_specific_filter=True (filter_detections.py:84-98): per-orientation threshold + NMS, concatenation in
+    orientation order, common top-k -- against goldens from the reference's own code, with and without NMS """
+    g = dict(np.load(os.path.join(helpers.GOLDEN, 'decode_{}.npz'.format(name))))
+    reg = to_fused(g['regression']) if fused else g['regression']
+    out = filter_detections(g['logits'], reg, g['regression_dim'], g['anchors'], fused_regression=fused, orientation_specific_filter=True)
+    for got, key in zip(out[:5], ('boxes', 'dimensions', 'scores', 'labels', 'orientations')):
+        assert got.dtype == g['osf_' + key].dtype and helpers.bits_equal(got, g['osf_' + key]), key
+    folded = np.maximum(g['classification'][..., :4], g['classification'][..., 4:])
+    assert np.array_equal(out[6], (folded > np.float32(0.05)).sum(axis=(1, 2)).astype(np.int32))      # candidates over the four lists
+    out = filter_detections(g['logits'], reg, g['regression_dim'], g['anchors'], fused_regression=fused, orientation_specific_filter=True,
+                            nms=False)
+    for got, key in zip(out[:5], ('boxes', 'dimensions', 'scores', 'labels', 'orientations')):
+        assert helpers.bits_equal(got, g['osfnonms_' + key]), 'nms=False ' + key
+
+
+@pytest.mark.parametrize('hw,batch,mean,std', [((96, 160), 3, -2.5, 1.0), ((402, 1333), 2, -4.2, 0.8)])
+def test_orientation_specific_filter_random_against_oracle(hw, batch, mean, std):
+    rng = np.random.default_rng(hw[0] * 7 + batch)
+    anchors = A.anchors_for_image(hw)
+    n = anchors.shape[0]
+    logits = rng.normal(mean, std, size=(batch, n, 8)).astype(np.float32)
+    logits[:, ::5, 1] = logits[:, ::5, 0]                     # exact score ties between orientations of one anchor
+    reg = rng.normal(0, 1, size=(batch, n, 12)).astype(np.float32)
+    dim = rng.normal(0, 1, size=(batch, n, 3)).astype(np.float32)
+    ref, ref_idx = decode_np.detect(logits, reg, dim, anchors, orientation_specific_filter=True)
+    out = filter_detections(logits, to_fused(reg), dim, anchors, fused_regression=True, orientation_specific_filter=True)
+    assert (ref[2] > 0).sum() > batch * 50
+    for got, want in zip(out[:5], ref):
+        assert helpers.bits_equal(got, want)
+    assert np.array_equal(out[5].astype(np.int64), ref_idx)

@@ -37,6 +37,11 @@ def test_oracle_decode_matches_reference_goldens(name):
         out, _ = decode_np.filter_detections(boxes[b], decode_np.regress_dims(g['regression_dim'])[b], g['classification'][b], nms=False)
         for got, key in zip(out, ('boxes', 'dimensions', 'scores', 'labels', 'orientations')):
             assert np.array_equal(got, g['nonms_' + key][b]), key
+        for prefix, kw in (('osf_', {}), ('osfnonms_', {'nms': False})):      # orientation_specific_filter=True (:84-98)
+            out, _ = decode_np.filter_detections(boxes[b], decode_np.regress_dims(g['regression_dim'])[b], g['classification'][b],
+                                                 orientation_specific_filter=True, **kw)
+            for got, key in zip(out, ('boxes', 'dimensions', 'scores', 'labels', 'orientations')):
+                assert got.dtype == g[prefix + key].dtype and np.array_equal(got, g[prefix + key][b]), prefix + key
 
 
 def test_goldens_cover_padding_empty_and_saturated_images():

@@ -168,6 +168,29 @@ def test_hip_graph_capture_replays_the_plan(monkeypatch):
             assert helpers.bits_equal(a, b)
 
 
+def test_orientation_specific_filter_through_the_model(monkeypatch):
+    """ models.load_model(..., orientation_specific_filter=True): same conv stack, per-orientation decode; checked against the
+    oracle's decode of the GPU's own head tensors, then polling against the C oracle """
+    monkeypatch.setenv('GPP_AUTOTUNE', '0')
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', orientation_specific_filter=True)
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    x = images(2, 160, 256, seed=5)
+    P = np.tile(P_inv[None].astype(np.float32), (2, 1, 1))
+    out = model.predict_on_batch([x, P, np.tile(planes[None], (2, 1, 1))])
+    plan = model.plan_for(2, 160, 256, planes.shape[0], True)
+    assert not plan.decode_overlap
+    cls = plan.cls_logits.cpu().numpy().reshape(2, -1, 8)
+    reg12 = unfuse(plan.regression.cpu().numpy())
+    det, _ = decode_np.detect(cls, reg12, plan.regression_dim.cpu().numpy().reshape(2, -1, 3), A.anchors_for_image((160, 256)),
+                              orientation_specific_filter=True)
+    assert (det[2] > 0.05).sum() > 0
+    for got, want in zip(out[:5], det):
+        assert helpers.bits_equal(got, want)
+    kp, kpl, res = polling_np.fit_road_planes(out[0], out[1], out[4], P, np.tile(planes[None], (2, 1, 1)))
+    assert np.array_equal(out[6], kpl) and np.allclose(out[5], kp, atol=1e-4) and np.allclose(out[7], res, atol=1e-5)
+
+
 def test_f16_storage_runs_and_agrees_with_bf16(model50):
     batch, h, w = 1, 96, 160
     img = images(batch, h, w, seed=5)
