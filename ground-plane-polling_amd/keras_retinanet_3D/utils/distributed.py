@@ -43,20 +43,24 @@ def unpack_outputs(packed):
     return out
 
 
-def gather_detections(packed_local, shard_sizes=None, group=None):
-    """ all-gather the packed detections of every rank -> (B_global, 100, 35) on every rank """
+def gather_detections(packed_local, shard_sizes=None, group=None, async_op=False):
+    """ all-gather the packed detections of every rank -> (B_global, 100, 35) on every rank.
+    async_op (equal shards on RCCL only): returns (tensor, work) without making the caller's stream wait for the
+    collective, so that the next step's kernels run while the gather is on the wire; call work.wait() before reading. """
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return packed_local
+        return (packed_local, None) if async_op else packed_local
     world = dist.get_world_size(group)
     if shard_sizes is None:
         shard_sizes = [packed_local.shape[0]] * world
     equal = len(set(shard_sizes)) == 1
     if equal and dist.get_backend(group) == 'nccl':
         out = torch.empty((sum(shard_sizes),) + tuple(packed_local.shape[1:]), dtype=packed_local.dtype, device=packed_local.device)
-        dist.all_gather_into_tensor(out, packed_local, group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, packed_local, group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    if async_op:
+        raise ValueError('async gather needs equal shards on the nccl (RCCL) backend')
     pad = max(shard_sizes)
     local = packed_local
     if local.shape[0] < pad:
