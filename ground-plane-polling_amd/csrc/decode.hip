@@ -689,6 +689,48 @@ int detect_impl(int stages, int lists_per_image, const float* cls_logits, const 
 
 }  // namespace
 
+namespace {
+
+// The eight result arrays of one image batch -> one (B, D, 35) float32 tensor (what the ranks exchange);
+// labels / orientations are small integers, exact in float32.
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ boxes, const float* __restrict__ dims,
+                                                   const float* __restrict__ scores, const int32_t* __restrict__ labels,
+                                                   const int32_t* __restrict__ orient, const float* __restrict__ keypoints,
+                                                   const float* __restrict__ keyplanes, const float* __restrict__ residuals,
+                                                   float* __restrict__ out, int64_t rows)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * 35) return;
+    const int64_t r = e / 35;
+    const int c = (int)(e - r * 35);
+    float v;
+    if (c < 12) v = boxes[r * 12 + c];
+    else if (c < 15) v = dims[r * 3 + (c - 12)];
+    else if (c == 15) v = scores[r];
+    else if (c == 16) v = (float)labels[r];
+    else if (c == 17) v = (float)orient[r];
+    else if (c < 30) v = keypoints[r * 12 + (c - 18)];
+    else if (c < 34) v = keyplanes[r * 4 + (c - 30)];
+    else v = residuals[r];
+    out[e] = v;
+}
+
+}  // namespace
+
+extern "C" int gpp_pack_detections(const float* boxes, const float* dims, const float* scores, const int32_t* labels,
+                                   const int32_t* orientations, const float* keypoints, const float* keyplanes,
+                                   const float* residuals, int B, int D, float* packed, void* stream)
+{
+    if (B < 0 || D < 0) return GPP_ERR_BAD_ARG;
+    if (B == 0 || D == 0) return GPP_OK;
+    if (!boxes || !dims || !scores || !labels || !orientations || !keypoints || !keyplanes || !residuals || !packed) return GPP_ERR_BAD_ARG;
+    const int64_t rows = (int64_t)B * D;
+    pack_kernel<<<dim3((unsigned)((rows * 35 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+        boxes, dims, scores, labels, orientations, keypoints, keyplanes, residuals, packed, rows);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}
+
 extern "C" int gpp_detect_workspace_bytes(int B, int64_t n_anchors, size_t* bytes)
 {
     if (!bytes || B < 0 || n_anchors <= 0) return GPP_ERR_BAD_ARG;

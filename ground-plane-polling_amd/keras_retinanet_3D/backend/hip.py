@@ -98,6 +98,8 @@ def _declare(lib):
     lib.gpp_detect_osf_workspace_bytes.argtypes = lib.gpp_detect_workspace_bytes.argtypes
     lib.gpp_detect_osf_f32.restype = c_int
     lib.gpp_detect_osf_f32.argtypes = lib.gpp_detect_f32.argtypes
+    lib.gpp_pack_detections.restype = c_int
+    lib.gpp_pack_detections.argtypes = [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p]
     lib.gpp_detect_stages_f32.restype = c_int
     lib.gpp_detect_stages_f32.argtypes = [c_int] + lib.gpp_detect_f32.argtypes
     lib.gpp_conv2d_flops.restype = c_int

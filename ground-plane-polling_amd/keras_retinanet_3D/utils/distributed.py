@@ -29,6 +29,12 @@ def pack_outputs(outputs):
     """ the 8 model outputs (torch tensors) -> one (B, 100, 35) float32 tensor (ints are small: exact) """
     import torch
     b, d = outputs[0].shape[:2]
+    if outputs[0].is_cuda and all(o.is_contiguous() for o in outputs):        # one launch of the library's pack kernel
+        from ..backend import hip
+        out = torch.empty((b, d, PACK_WIDTH), dtype=torch.float32, device=outputs[0].device)
+        hip.check(hip.lib().gpp_pack_detections(*([hip.ptr(o) for o in outputs] + [int(b), int(d), hip.ptr(out), hip.stream_ptr()])),
+                  'gpp_pack_detections')
+        return out
     return torch.cat([o.reshape(b, d, -1).to(torch.float32) for o in outputs], dim=2).contiguous()
 
 

@@ -266,6 +266,12 @@ int gpp_detect_osf_f32(const float* cls_logits, const float* regression, const f
                        int32_t* anchor_index, int32_t* counts,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* The eight result arrays -> one (B, D, 35) float32 tensor [12 box | 3 dim | score | label | orientation | 12 keypoints |
+ * 4 plane | residual]: the unit of the per-step exchange between the ranks of a node (one all-gather). */
+int gpp_pack_detections(const float* boxes, const float* dims, const float* scores, const int32_t* labels,
+                        const int32_t* orientations, const float* keypoints, const float* keyplanes,
+                        const float* residuals, int B, int D, float* packed, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Plan execution: one call enqueues a whole predict_on_batch (every kernel of the graph that
  * models/retinanet.py:359-422 `retinanet_bbox` builds) from a host array of descriptors.

@@ -191,6 +191,23 @@ def test_orientation_specific_filter_through_the_model(monkeypatch):
     assert np.array_equal(out[6], kpl) and np.allclose(out[5], kp, atol=1e-4) and np.allclose(out[7], res, atol=1e-5)
 
 
+def test_pack_kernel_equals_the_torch_concatenation(model50):
+    """ gpp_pack_detections (one launch) == torch.cat of the eight arrays; unpack restores them exactly """
+    import torch
+    from keras_retinanet_3D.utils import distributed as D
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    x = images(2, 160, 256, seed=2)
+    out = model50.predict_on_batch([x, np.tile(P_inv[None].astype(np.float32), (2, 1, 1)), np.tile(planes[None], (2, 1, 1))])
+    plan = model50.plan_for(2, 160, 256, planes.shape[0], True)
+    dev_outs = model50.outputs(plan)
+    packed = D.pack_outputs(dev_outs)
+    ref = torch.cat([o.reshape(2, 100, -1).to(torch.float32) for o in dev_outs], dim=2)
+    assert packed.shape == (2, 100, 35) and torch.equal(packed.cpu().view(torch.int32), ref.cpu().view(torch.int32))
+    for a, b in zip(D.unpack_outputs(packed), out):
+        assert a.dtype == b.dtype and helpers.bits_equal(a, b) if a.dtype.kind == 'f' else np.array_equal(a, b)
+
+
 def test_f16_storage_runs_and_agrees_with_bf16(model50):
     batch, h, w = 1, 96, 160
     img = images(batch, h, w, seed=5)
