@@ -184,7 +184,7 @@ __device__ __forceinline__ RowAddr row_addr(const gpp_conv_desc& d, int m, int H
 }
 
 template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_conv_desc d)
+__device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const int block_x, const int grid_x)
 {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     GPP_STAMP(0);
 
     // ---- which tile
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(block_x, grid_x);
     const int n_tiles = (d.C_out + BN - 1) / BN;
     const int nt = bid % n_tiles, mt = bid / n_tiles;
     int tile_start = 0, H_in = 0, W_in = 0, H_out = 0, W_out = 0, H_res = 0, W_res = 0;
@@ -567,6 +567,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     GPP_STAMP(4);
+}
+
+template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_conv_desc d)
+{
+    conv_igemm_body<DT, BM, BN, WM, WN, STAGES, PIPE>(d, blockIdx.x, gridDim.x);
+}
+
+// A layer whose C_out is an odd multiple of 128 (the fused tower inputs: 896 = 3 x 256 + 128) in ONE grid of two tile
+// shapes: workgroups [0, n0) cover the first C_out - 128 columns with 256 x 256 tiles (descriptor d0), workgroups
+// [split0, split0 + n1) the last 128 columns with the same kernel turned on its side, 512 x 128 tiles (descriptor d1 = the
+// same layer with its weight / bias / output pointers moved to that column block).  Every workgroup does the same amount
+// of matrix work, none of it on padding, and the hardware hands the second range out behind the first, into the CUs its
+// last partial round leaves idle: 1253 workgroups = 5 rounds instead of 1432 = 6 for the 896-column layer.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void conv_igemm_dual_kernel(const gpp_conv_desc d0, const gpp_conv_desc d1, const int n0,
+                                                                 const int split0, const int n1)
+{
+    if ((int)blockIdx.x < split0) {
+        if ((int)blockIdx.x < n0) conv_igemm_body<DT, 256, 256, 2, 4, 2, true>(d0, blockIdx.x, n0);
+    } else {
+        conv_igemm_body<DT, 512, 128, 4, 2, 2, true>(d1, (int)blockIdx.x - split0, n1);
+    }
 }
 
 // Second pass of a split-K launch: sum the partial slabs in split order (deterministic), then the
@@ -958,18 +981,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
     GPP_STAMP(4);
 }
 
-// One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.
-template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
-int launch(gpp_conv_desc& d, hipStream_t st)
+// Fill in what the kernel needs beyond the caller's fields (buffer extents, first tile of every group); returns the
+// number of M tiles or a negative error.
+template <int BM, int BN>
+int prepare(gpp_conv_desc& d)
 {
-    constexpr int lds = STAGES * (BM + BN) * kRowBytes;
-    static bool configured = false;
-    auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES, PIPE>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
     if (d.weight_rows < ((d.C_out + BN - 1) / BN) * BN) return GPP_ERR_BAD_ARG;
     int64_t in_elems = 0;
     for (int g = 0; g < d.n_groups; ++g) {
@@ -987,6 +1003,24 @@ int launch(gpp_conv_desc& d, hipStream_t st)
         d.groups[g].tile_start = tiles;
         tiles += (d.batch * d.groups[g].H_out * d.groups[g].W_out + BM - 1) / BM;
     }
+    d.partial_rows = tiles * BM;
+    return tiles;
+}
+
+// One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.
+template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
+int launch(gpp_conv_desc& d, hipStream_t st)
+{
+    constexpr int lds = STAGES * (BM + BN) * kRowBytes;
+    static bool configured = false;
+    auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES, PIPE>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const int tiles = prepare<BM, BN>(d);
+    if (tiles < 0) return tiles;
     const int n_tiles = (d.C_out + BN - 1) / BN;
     // split-K when the tile grid leaves most of the 256 CUs idle and K is deep: every split keeps
     // >= 8 K-steps; partial slabs [split][tiles*BM][n_tiles*BN] float32 must fit the workspace
@@ -1000,7 +1034,6 @@ int launch(gpp_conv_desc& d, hipStream_t st)
         while (want > 1 && slab * want > (int64_t)d.partial_bytes) --want;
         nsplit = want < 1 ? 1 : want;
     }
-    d.partial_rows = tiles * BM;
     // a layer with fewer K-steps than ring slots (1x1 convs with C_in = 64) only touches the first slots:
     // declaring just those lets more workgroups share a CU, which is what the HBM-bound layers need
     const int steps = (nk + nsplit - 1) / nsplit;
@@ -1010,6 +1043,40 @@ int launch(gpp_conv_desc& d, hipStream_t st)
         const int64_t total = (int64_t)d.partial_rows * ((d.C_out + 7) / 8);
         splitk_reduce_kernel<DT><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(d, BM, n_tiles * BN, nsplit);
     }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}
+
+// conv_igemm_dual_kernel: C_out = 256 k + 128.  The caller's descriptor is split into the two column blocks here.
+template <int DT>
+int launch_dual(const gpp_conv_desc& d, hipStream_t st)
+{
+    if (d.C_out < 384 || d.C_out % 256 != 128 || d.KH * d.KW * (d.C_in / 64) < 2) return GPP_ERR_UNSUPPORTED;
+    constexpr int lds = 2 * (512 + 128) * kRowBytes;          // 160 KB: the larger of the two bodies
+    static bool configured = false;
+    auto kernel = conv_igemm_dual_kernel<DT>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const int head = d.C_out - 128;                           // columns of the 256-wide part: a multiple of 256
+    gpp_conv_desc d0 = d, d1 = d;
+    d0.C_out = head;
+    d1.C_out = 128;
+    d1.weight = (const char*)d.weight + (int64_t)head * d.KH * d.KW * d.C_in * 2;
+    d1.weight_rows = d.weight_rows - head;
+    if (d.bias) d1.bias = d.bias + head;
+    for (int g = 0; g < d.n_groups; ++g) {
+        d1.groups[g].out_off += head;
+        d1.groups[g].res_off += head;
+    }
+    const int t0 = prepare<256, 256>(d0), t1 = prepare<512, 128>(d1);
+    if (t0 < 0) return t0;
+    if (t1 < 0) return t1;
+    const int n0 = t0 * (head / 256), n1 = t1;
+    const int split0 = (n0 + 7) / 8 * 8;                      // keeps workgroup index % 8 = XCD for the second range's remap
+    kernel<<<dim3((unsigned)(split0 + n1)), dim3(512), lds, st>>>(d0, d1, n0, split0, n1);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }
@@ -1042,6 +1109,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
         case 128160: return launch<DT, 128, 160, 4, 1, 2, false>(d, st);
         case 192160: return launch<DT, 192, 160, 4, 1, 2, false>(d, st);
         case 1192160: return launch<DT, 192, 160, 4, 1, 2, true>(d, st);
+        case 2256256: return launch_dual<DT>(d, st);            // 256 x 256 tiles + 512 x 128 tiles for the last 128 columns, one grid
         case 512:
         case 256256: return (d.reserved & 8) ? launch<DT, 256, 256, 2, 4, 2, false>(d, st) : launch<DT, 256, 256, 2, 4, 2, true>(d, st);
         case 0: break;
@@ -1212,7 +1280,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     if (!desc || iters < 1) return GPP_ERR_BAD_ARG;
     static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                                  1128128, 1192128, 1128256, 1192256, 256256,
-                                 128160, 192160, 1192160};
+                                 128160, 192160, 1192160, 2256256};
     static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
@@ -1251,6 +1319,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) continue;
         if (tile > 1000000 && nk < 4) continue;                      // the pipelined loop needs a few K-steps to pay
         if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding
+        if (tile == 2256256 && (desc->C_out < 384 || desc->C_out % 256 != 128 || rows < 256 * 16)) continue;   // dual-shape grid: C_out = 256 k + 128
         float us = 0.0f;
         int r = time_one(tile, tile == 0 ? split_in : 1, &us);
         if (r != GPP_OK) { if (tile == 0) { rc = r; break; } continue; }

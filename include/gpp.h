@@ -134,7 +134,8 @@ typedef struct gpp_conv_desc {
     int32_t n_groups;
     int32_t tile_hint;              /* 0 = library heuristic; BM*1000 + BN forces a block tile (64..224 x 64/128, 128/192 x 160,
                                        256256), + 1000000 = the software-pipelined main loop (128128, 192128, 128256, 192256,
-                                       192160); legacy codes 64 / 128 / 256 / 512; anything else: GPP_ERR_BAD_ARG.
+                                       192160), 2256256 = 256256 plus 512 x 128 tiles for the last 128 columns in one grid
+                                       (C_out = 256 k + 128 only); legacy codes 64 / 128 / 256 / 512; anything else: GPP_ERR_BAD_ARG.
                                        See gpp_conv2d_autotune */
     int32_t reserved;               /* 0.  Timing experiments only (tools/bench_conv.py): bit 0 skip the tile loads, bit 1 skip
                                        the LDS reads + MFMA, bit 2 / 3 flip the pipelined form of the 128128 / 256256 tile;

@@ -343,3 +343,34 @@ def test_bottleneck_tail_next_equals_the_three_layers(cmid, B, H, W, dtype, tile
     # the third descriptor must read the map the second one writes
     assert hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2f), ctypes.byref(d3), tile_rows, hip.stream_ptr()) == -1
     assert hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2f), None, tile_rows, hip.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('cin,cout,relu,f32', [(128, 384, True, False), (64, 896, True, False), (64, 640, False, True)])
+def test_dual_shape_grid_equals_the_plain_tile(cin, cout, relu, f32, dtype):
+    """ tile code 2256256 (C_out = 256 k + 128): 256 x 256 tiles for the first C_out - 128 columns and 512 x 128 tiles for the
+    last 128 in one grid -- the bits of the ordinary launch, over several feature maps with ragged row counts """
+    g = torch.Generator().manual_seed(cout)
+    tdt = C.torch_dtype(dtype)
+    dev = torch.device('cuda')
+    B, shapes = 2, [(21, 29), (11, 15), (6, 8), (3, 4)]
+    total = sum(h * w for h, w in shapes)
+    x = torch.randn((B, total, cin), generator=g).to(tdt).to(dev)
+    w = C.pack_weight((torch.randn((3, 3, cin, cout), generator=g) * (2.0 / (9 * cin)) ** 0.5).numpy(), dtype, dev)
+    b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    results = []
+    for tile in (128128, 2256256):
+        o = torch.full((B, total, cout), float('nan'), dtype=torch.float32 if f32 else tdt, device=dev)
+        ins, outs, off = [], [], 0
+        for h, wd in shapes:
+            ins.append(C.FMap(x, B, h, wd, cin, off=off * cin, bstride=total * cin))
+            outs.append(C.FMap(o, B, h, wd, cout, off=off * cout, bstride=total * cout))
+            off += h * wd
+        C.run_conv(C.conv_desc(ins, outs, w, b, 3, 3, cin, cout, pad=(1, 1), relu=relu, dtype=dtype, out_f32=f32, tile_hint=tile))
+        results.append(o.float().cpu())
+    assert not torch.isnan(results[1]).any() and torch.equal(results[0], results[1])
+    # other widths are refused
+    o = torch.empty((B, total, 256), dtype=tdt, device=dev)
+    w2 = C.pack_weight((torch.randn((3, 3, cin, 256), generator=g) * 0.05).numpy(), dtype, dev)
+    d = C.conv_desc([C.FMap(x, B, total, 1, cin)], [C.FMap(o, B, total, 1, 256)], w2, b[:256].contiguous(), 3, 3, cin, 256, pad=(1, 1), dtype=dtype, tile_hint=2256256)
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -4

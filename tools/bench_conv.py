@@ -128,6 +128,11 @@ if __name__ == '__main__':
             print('   first wave of workgroups: %d started within 1 us; their mean setup/main/epi/drain: %s' %
                   (first.sum(), ' '.join('%.2f' % v for v in dur[order][first].mean(axis=0))))
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'towers0':
+        for rep in range(2):
+            for tile in (256256, 2256256):
+                bench('towers_0 3x3 512->896 t%d' % tile, B, PYR, 512, 896, 3, tile=tile, iters=20)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'prio':
         for rep in range(3):
             for diag, what in ((0, 'base'),):
