@@ -1,1204 +1,75 @@
-// NHWC convolution as an implicit GEMM on the gfx950 matrix cores (v_mfma_f32_16x16x32_{bf16,f16}),
-// no im2col buffer, fused bias / residual (+ nearest resize) / ReLU epilogue.
+// C ABI of the implicit-GEMM convolution (include/gpp.h): argument validation, the batch-independent split-K rule,
+// dispatch to the per-element-type kernels (conv_igemm_{bf16,f16,f32}.hip <- conv_igemm_impl.h) and the tile autotuner.
 //
 // Replaces the Conv2D / BatchNormalization(frozen) / Activation / Add / UpsampleLike nodes of
 //   /root/reference/keras_retinanet_3D/models/retinanet.py:24-205  (heads, FPN)
 //   keras_resnet bottleneck stack used at models/resnet.py:88-93     (third party)
-// for every layer with C_in % 64 == 0 (everything except the 3-channel stem, csrc/stem.hip).
-//
-// GEMM view (one launch = up to 5 feature maps sharing the weights):
-//   C[M = batch*Ho*Wo pixels][N = C_out] = A[M][K] * B[K][N],  K = (c_in chunk of 64, kh, kw, 64 channels)
-//   A is never materialised: for K-step (64-channel chunk, tap) row m is the 128 contiguous bytes
-//   in[b, oy*s - pt + kh, ox*s - pl + kw, c0:c0+64]; outside the image the buffer descriptor's range check
-//   makes the LDS-DMA deliver zeros.
-//
-// Work decomposition
-//   block tile BM x BN with WM x WN wavefronts and a STAGES-deep LDS ring, three configurations:
-//     256 x 256, 2 x 4 wavefronts (wave tile 128 x 64 = 8 x 4 MFMA 16x16 accumulators), 2 buffers, software-
-//               pipelined + explicitly interleaved main loop (PIPE): the big 3x3 layers, 1 workgroup / CU
-//     128 x 128 and 128 x 64, 2 x 2 wavefronts, 2 buffers: everything else, 2+ workgroups / CU, optional split-K
-//   K-step = 64 channels of one tap; A and B tiles (128-byte rows) go L2 -> LDS with buffer_load ... lds
-//   (LDS-DMA, no VGPR staging): per-lane offset fixed per tap, per-step offset scalar.
-//   LDS rows are XOR-swizzled in 16-byte chunks (chunk ^= row & 7) by permuting the *source* chunk each
-//   lane fetches (the LDS-DMA destination is lane-linear): conflict-free ds_read_b128 fragment reads.
-//   Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous range of tiles;
-//   the N-tiles of one M-tile are adjacent, so the activation rows are shared in that L2.
-//   Epilogue: straight from the accumulators (operands swapped + host-interleaved weight rows give
-//   every lane 8 consecutive output channels): bias, residual (+ nearest resize), ReLU, 16-byte stores.
-//   Split-K (gridDim.y) writes float32 partial tiles; splitk_reduce_kernel sums them in split order and
-//   runs the same epilogue.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "conv_igemm_types.h"
 #include "gpp.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-template <int DT> struct Elem;
-template <> struct Elem<GPP_BF16> {
-    using scalar = __bf16;
-    using vec8 = bf16x8;
-    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c)
-    {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Elem<GPP_F16> {
-    using scalar = _Float16;
-    using vec8 = f16x8;
-    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c)
-    {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-    }
-};
-
-constexpr int kRowBytes = 128;     // one K-step of one tile row: 64 two-byte elements
-
-// LDS-DMA through a buffer descriptor: 16 bytes per lane from base + voffset + soffset to
-// lds_dst_wave_base + lane*16.  voffset is per lane, soffset wave-uniform (SGPR), so the per-K-step
-// address arithmetic is scalar; a lane whose voffset is out of range (kOutOfRange) gets zeros,
-// which is how convolution padding is produced without a zero page or per-step predication.
-__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, void* lds_dst_wave_base)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16,
-                                             voffset, soffset, 0, 0);
-}
-
-constexpr int kOutOfRange = (int)0x80000000;
-
-// Diagnostic build only (-DGPP_STAMPS, tools/bench_conv.py stamps): wave 0 of every workgroup writes the 100 MHz
-// real-time counter at five points into a buffer of its own (handed in through the otherwise unused zero_page
-// field when reserved bit 4 is set).  No output depends on it; the production build contains none of this.
-#ifdef GPP_STAMPS
-#define GPP_STAMP(k)                                                                                          \
-    do {                                                                                                      \
-        if ((d.reserved & 16) && wave == 0 && lane == 0)                                                      \
-            ((unsigned long long*)d.zero_page)[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define GPP_STAMP(k) do { } while (0)
-#endif
-
-// Bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous tile range.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg)
-{
-    const int xcd = bid & 7, local = bid >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-}
-
-// Finish 8 consecutive output channels of one output pixel: (+ residual through the optional TF
-// nearest resize) (+ ReLU), convert, store.  v already holds accumulator + bias.
-template <int DT>
-__device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], int n, int64_t obase,
-                                        const typename Elem<DT>::scalar* rrow)
-{
-    using vec8 = typename Elem<DT>::vec8;
-    using scalar = typename Elem<DT>::scalar;
-    const bool full = (n + 8 <= d.C_out);
-    if (rrow) {
-        if (full) {
-            const vec8 rv = *(const vec8*)(rrow + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-        } else {
-            for (int e = 0; e < 8 && n + e < d.C_out; ++e) v[e] += (float)rrow[n + e];
-        }
-    }
-    if (d.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-    }
-    if (d.out_f32) {
-        float* dst = (float*)d.out + obase + n;
-        if (full) {
-            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-            *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-        } else {
-            for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = v[e];
-        }
-    } else {
-        scalar* dst = (scalar*)d.out + obase + n;
-        if (full) {
-            vec8 ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = (scalar)v[e];
-            *(vec8*)dst = ov;
-        } else {
-            for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = (scalar)v[e];
-        }
-    }
-}
-
-// finish8 with the residual already in registers (prefetched): same arithmetic, so the same bits.  Full groups only.
-template <int DT>
-__device__ __forceinline__ void finish8_pre(const gpp_conv_desc& d, float (&v)[8], int n, int64_t obase, bool has_res,
-                                            const typename Elem<DT>::vec8 rv)
-{
-    using vec8 = typename Elem<DT>::vec8;
-    using scalar = typename Elem<DT>::scalar;
-    if (has_res) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-    }
-    if (d.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-    }
-    if (d.out_f32) {
-        float* dst = (float*)d.out + obase + n;
-        *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-        *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-    } else {
-        scalar* dst = (scalar*)d.out + obase + n;
-        vec8 ov;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = (scalar)v[e];
-        *(vec8*)dst = ov;
-    }
-}
-
-// Where output row m of a group lives (and its residual row).
-struct RowAddr { int64_t obase; int64_t rbase; };
-__device__ __forceinline__ RowAddr row_addr(const gpp_conv_desc& d, int m, int HoWo, int W_out, int H_out, int H_res, int W_res,
-                                            int64_t out_off, int64_t out_bs, int64_t res_off, int64_t res_bs)
-{
-    const int b = m / HoWo, p = m - b * HoWo;
-    int64_t rp = p;
-    if (d.residual && (H_res != H_out || W_res != W_out)) {
-        const float sy = (float)H_res / (float)H_out, sx = (float)W_res / (float)W_out;
-        const int oy = p / W_out, ox = p - oy * W_out;
-        const int ry = min((int)floorf((float)oy * sy), H_res - 1);
-        const int rx = min((int)floorf((float)ox * sx), W_res - 1);
-        rp = (int64_t)ry * W_res + rx;
-    }
-    RowAddr a;
-    a.obase = out_off + (int64_t)b * out_bs + (int64_t)p * d.out_pitch;
-    a.rbase = res_off + (int64_t)b * res_bs + rp * d.res_pitch;
-    return a;
-}
-
-template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
-__device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const int block_x, const int grid_x)
-{
-    using E = Elem<DT>;
-    using vec8 = typename E::vec8;
-    using scalar = typename E::scalar;
-    constexpr int NW = WM * WN;                          // wavefronts per workgroup
-    constexpr int MF = BM / WM / 16, NF = BN / WN / 16;  // 16x16 accumulators per wave: MF x NF
-    constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;   // LDS-DMA instructions per wave per stage
-    constexpr int PER_STAGE = A_IT + B_IT;
-    constexpr int PF = STAGES - 1;                       // K-steps in flight ahead of the one computed
-    static_assert(MF >= 1 && NF >= 1 && A_IT >= 1 && B_IT >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WM) == 0, "tile / wave shape");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    GPP_STAMP(0);
-
-    // ---- which tile
-    const int bid = xcd_remap(block_x, grid_x);
-    const int n_tiles = (d.C_out + BN - 1) / BN;
-    const int nt = bid % n_tiles, mt = bid / n_tiles;
-    int tile_start = 0, H_in = 0, W_in = 0, H_out = 0, W_out = 0, H_res = 0, W_res = 0;
-    int64_t in_off = 0, in_bs = 0, out_off = 0, out_bs = 0, res_off = 0, res_bs = 0;
-#pragma unroll
-    for (int q = 0; q < GPP_MAX_GROUPS; ++q) {
-        if (q < d.n_groups && mt >= d.groups[q].tile_start) {
-            tile_start = d.groups[q].tile_start;
-            H_in = d.groups[q].H_in; W_in = d.groups[q].W_in;
-            H_out = d.groups[q].H_out; W_out = d.groups[q].W_out;
-            H_res = d.groups[q].H_res; W_res = d.groups[q].W_res;
-            in_off = d.groups[q].in_off; in_bs = d.groups[q].in_bstride;
-            out_off = d.groups[q].out_off; out_bs = d.groups[q].out_bstride;
-            res_off = d.groups[q].res_off; res_bs = d.groups[q].res_bstride;
-        }
-    }
-    const int HoWo = H_out * W_out;
-    const int Mg = d.batch * HoWo;
-    const int m0 = (mt - tile_start) * BM, n0 = nt * BN;
-    const int Ktot = d.KH * d.KW * d.C_in;
-    const int cpt = d.C_in >> 6;                        // 64-channel chunks per tap
-    const int nk_total = d.KH * d.KW * cpt;
-    // split-K: blockIdx.y owns K-steps [ks0, ks0 + nk); partial sums go to d.partial, the epilogue runs
-    // in splitk_reduce_kernel
-    const int nsplit = gridDim.y, split = blockIdx.y;
-    const int ks0 = (int)((int64_t)nk_total * split / nsplit);
-    const int nk = (int)((int64_t)nk_total * (split + 1) / nsplit) - ks0;
-
-    // ---- staging bookkeeping: this lane owns LDS chunk (row srow of each 8-row piece, slot lane&7)
-    // and fetches source chunk gchunk = slot ^ srow (inverse of the read swizzle).  Byte offsets are
-    // relative to d.in / d.weight and go through buffer descriptors (32-bit, range checked).
-    const int srow = lane >> 3;
-    const int gchunk = (lane & 7) ^ srow;
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, d.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.weight, 0, d.weight_bytes, 0x00020000);
-    // Per staged row: byte offset of its tap (0,0) source (may be negative at the border -- it is
-    // only used when the tap is valid) and a validity mask: bit kh = input row iy0+kh inside the
-    // image, bit 8+kw = input column ix0+kw inside.  Per K-step the source is base + (kh*W + kw)*pitch
-    // (a scalar) when both bits are set, else kOutOfRange: ~4 VALU per row and step.
-    int a_base[A_IT], a_mask[A_IT], a_voff[A_IT];
-    const int pitch2 = d.in_pitch * 2;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + (wave * A_IT + i) * 8 + srow;
-        a_mask[i] = 0;
-        a_base[i] = 0;
-        if (m < Mg) {
-            const int b = m / HoWo, p = m - b * HoWo;
-            const int oy = p / W_out, ox = p - oy * W_out;
-            const int iy0 = oy * d.stride - d.pad_top, ix0 = ox * d.stride - d.pad_left;
-            int mask = 0;
-            for (int k = 0; k < d.KH; ++k) mask |= ((unsigned)(iy0 + k) < (unsigned)H_in) << k;
-            for (int k = 0; k < d.KW; ++k) mask |= ((unsigned)(ix0 + k) < (unsigned)W_in) << (8 + k);
-            a_mask[i] = mask;
-            a_base[i] = (int)((in_off + (int64_t)b * in_bs) * 2) + gchunk * 16 + (iy0 * W_in + ix0) * pitch2;
-        }
-    }
-    int w_voff[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) w_voff[i] = (n0 + (wave * B_IT + i) * 8 + srow) * Ktot * 2 + gchunk * 16;
-
-    auto set_tap = [&](int kh, int kw) {
-        const int delta = (kh * W_in + kw) * pitch2;
-        const int need = (1 << kh) | (1 << (8 + kw));
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) a_voff[i] = ((a_mask[i] & need) == need) ? a_base[i] + delta : kOutOfRange;
-    };
-    // per K-step: only scalar offsets change (cc*128 bytes into the pixel, ks*128 bytes into the weight row)
-    auto stage = [&](int buf, int cc, int ks) {
-        unsigned char* sa = smem + buf * STAGE + wave * A_IT * 8 * kRowBytes;
-        unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) glds16(in_rsrc, a_voff[i], cc * kRowBytes, sa + i * 8 * kRowBytes);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(w_rsrc, w_voff[i], ks * kRowBytes, sb + i * 8 * kRowBytes);
-    };
-
-    // ---- fragment read offsets (bytes inside a stage)
-    const int frow = lane & 15, fq = lane >> 4;
-    int a_rd[2], b_rd[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int sw = ((kk * 4 + fq) ^ (frow & 7)) << 4;
-        a_rd[kk] = (wm * (BM / WM) + frow) * kRowBytes + sw;
-        b_rd[kk] = A_BYTES + (wn * (BN / WN) + frow) * kRowBytes + sw;
-    }
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ---- shortcut prefetch (small non-pipelined tiles only: the layers that carry a residual are the 1x1 "branch2c" /
-    // FPN lateral convs with 4-16 K-steps, where load -> wait -> add -> store in the epilogue is a large part of a
-    // workgroup's life): the residual rows of this tile are requested now and are in registers when the loop ends
-    constexpr bool RESPRE = !PIPE && (MF * NF / 2 <= 10);
-    vec8 rpre[RESPRE ? MF : 1][RESPRE ? NF / 2 : 1];
-    RowAddr ra_pre[RESPRE ? MF : 1];
-    const bool use_pre = RESPRE && d.residual != nullptr && gridDim.y == 1 && (d.C_out & 7) == 0;
-    if constexpr (RESPRE) {
-        if (use_pre) {
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
-                ra_pre[i] = row_addr(d, m < Mg ? m : 0, HoWo, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
-#pragma unroll
-                for (int jj = 0; jj < NF / 2; ++jj) {
-                    const int n = n0 + wn * (BN / WN) + jj * 32 + (lane >> 4) * 8;
-                    rpre[i][jj] = *(const vec8*)((const scalar*)d.residual + ra_pre[i].rbase + (n < d.C_out ? n : 0));
-                }
-            }
-        }
-    }
-
-    GPP_STAMP(1);
-    // ---- main loop.  Ring of STAGES buffers, PF = STAGES-1 K-steps of LDS-DMA in flight; one raw
-    // s_barrier per K-step.  At the top of step ks a counted vmcnt retires this wave's loads of
-    // stage ks only (later stages stay in flight across the barrier); after the barrier every
-    // wave's loads of stage ks have landed and every wave has finished reading the buffer of step
-    // ks-1, which is exactly the buffer the next prefetch (stage ks+PF) overwrites.
-    // K order: 64-channel chunk OUTER, tap INNER (weights are packed to match): the nine taps of one
-    // chunk re-read the same few input rows back to back, so they hit in the XCD's L2 instead of being
-    // re-fetched across the fabric once per tap
-    const int taps = d.KH * d.KW;
-    int cc = ks0 / taps, kw = (ks0 % taps) % d.KW, kh = (ks0 % taps) / d.KW, issued = 0, ibuf = 0;
-    set_tap(kh, kw);
-    auto issue_next = [&]() {
-        stage(ibuf, cc, ks0 + issued);
-        if (++kw == d.KW) {
-            kw = 0;
-            if (++kh == d.KH) { kh = 0; ++cc; }
-        }
-        set_tap(kh, kw);
-        ++issued;
-        if (++ibuf == STAGES) ibuf = 0;
-    };
-    auto load_frags = [&](vec8 (&af)[MF], vec8 (&bfr)[NF], int buf, int kk) {
-        const unsigned char* sbase = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < MF; ++i) af[i] = *(const vec8*)(sbase + a_rd[kk] + i * 16 * kRowBytes);
-#pragma unroll
-        for (int j = 0; j < NF; ++j) bfr[j] = *(const vec8*)(sbase + b_rd[kk] + j * 16 * kRowBytes);
-    };
-    auto mfma_all = [&](const vec8 (&af)[MF], const vec8 (&bfr)[NF]) {
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[i][j] = E::mfma(bfr[j], af[i], acc[i][j]);
-    };
-
-    if constexpr (PIPE) {
-        // Software-pipelined, explicitly interleaved form (two LDS buffers).  Per K-step k:
-        //   phase 0:  MFMA(kk=0 of k)  ||  LDS reads of kk=1 of k
-        //   wait stage k+1 landed, lgkmcnt(0), s_barrier      (everyone is done reading buffer k&1)
-        //   phase 1:  MFMA(kk=1 of k)  ||  LDS-DMA of stage k+2 into buffer k&1  ||  LDS reads of kk=0 of k+1
-        // Each phase is cut into MF groups {PER_STAGE/MF LDS-DMA, 1-2 ds_read_b128, NF MFMA} pinned with
-        // sched_barrier, so the ~100-cycle issue cost of every LDS-DMA and the LDS read latency sit
-        // under matrix-pipe work instead of in front of it.  In the tail the DMA goes through a
-        // zero-length descriptor (dropped by the range check) and the look-ahead reads hit a buffer
-        // nobody uses: no branches inside the interleaved region.
-        static_assert(STAGES == 2, "pipelined loop: two buffers");
-        const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, 0, 0x00020000);
-        auto issue_one = [&](int idx, int buf, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int so_a, int so_w) {
-            unsigned char* sa = smem + buf * STAGE + wave * A_IT * 8 * kRowBytes;
-            unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
-            if (idx < A_IT) glds16(ra, a_voff[idx < A_IT ? idx : 0], so_a, sa + idx * 8 * kRowBytes);
-            else glds16(rw, w_voff[idx >= A_IT ? idx - A_IT : 0], so_w, sb + (idx - A_IT) * 8 * kRowBytes);
-        };
-        auto advance_tap = [&]() {
-            if (++kw == d.KW) {
-                kw = 0;
-                if (++kh == d.KH) { kh = 0; ++cc; }
-            }
-            set_tap(kh, kw);
-            ++issued;
-        };
-        vec8 a0[MF], b0[NF], a1[MF], b1[NF];
-        // prologue: stage 0 -> buffer 0, wait, stage 1 -> buffer 1, fragments kk=0 of step 0
-#pragma unroll
-        for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 0, in_rsrc, w_rsrc, cc * kRowBytes, ks0 * kRowBytes);
-        advance_tap();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        {
-            const bool live = issued < nk;
-            const __amdgpu_buffer_rsrc_t ra = live ? in_rsrc : null_rsrc, rw = live ? w_rsrc : null_rsrc;
-#pragma unroll
-            for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 1, ra, rw, cc * kRowBytes, (ks0 + issued) * kRowBytes);
-            if (live) advance_tap();
-        }
-        load_frags(a0, b0, 0, 0);
-        // static priority for the later-dispatched half of an 8-wavefront workgroup: it loses every issue arbitration to
-        // its SIMD partner otherwise (measured +0.5 ... 2 % on the 256 x 256 tile; no effect on results)
-        if (NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-        for (int ks = 0; ks < nk; ++ks) {
-#ifdef GPP_STAMPS
-            if ((d.reserved & 32) && blockIdx.x < 64 && ks < 120 && wave == 0 && lane == 0)     // per-K-step timeline of a few workgroups
-                ((unsigned long long*)d.zero_page)[(1 << 19) + blockIdx.x * 128 + ks] = __builtin_amdgcn_s_memrealtime();
-#endif
-            const int cur = ks & 1;
-            const unsigned char* scur = smem + cur * STAGE;
-            const unsigned char* snxt = smem + (cur ^ 1) * STAGE;
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- phase 0
-#pragma unroll
-            for (int g = 0; g < MF; ++g) {
-                a1[g] = *(const vec8*)(scur + a_rd[1] + g * 16 * kRowBytes);
-#pragma unroll
-                for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) b1[j] = *(const vec8*)(scur + b_rd[1] + j * 16 * kRowBytes);
-#pragma unroll
-                for (int j = 0; j < NF; ++j) acc[g][j] = E::mfma(b0[j], a0[g], acc[g][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const bool live = issued < nk;
-            const __amdgpu_buffer_rsrc_t ra = live ? in_rsrc : null_rsrc, rw = live ? w_rsrc : null_rsrc;
-            const int so_a = cc * kRowBytes, so_w = (ks0 + issued) * kRowBytes;
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- phase 1
-#pragma unroll
-            for (int g = 0; g < MF; ++g) {
-#pragma unroll
-                for (int idx = g * PER_STAGE / MF; idx < (g + 1) * PER_STAGE / MF; ++idx) issue_one(idx, cur, ra, rw, so_a, so_w);
-                a0[g] = *(const vec8*)(snxt + a_rd[0] + g * 16 * kRowBytes);
-#pragma unroll
-                for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) b0[j] = *(const vec8*)(snxt + b_rd[0] + j * 16 * kRowBytes);
-#pragma unroll
-                for (int j = 0; j < NF; ++j) acc[g][j] = E::mfma(b1[j], a1[g], acc[g][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (live) advance_tap();         // a_voff for the next issue changes only after this step's DMA is out
-        }
-        if (NW == 8) __builtin_amdgcn_s_setprio(0);
-    } else {
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
-        if (issued < nk) issue_next();
-    int cbuf = 0;
-    // (diagnostic build: four stamps per K-step of the first 64 workgroups -- top, after the wait, after the barrier,
-    // after the LDS-DMA issue; the MFMA part runs up to the next top)
-#ifdef GPP_STAMPS
-#define GPP_KSTAMP(j)                                                                                                  \
-    do {                                                                                                               \
-        if ((d.reserved & 32) && blockIdx.x < 64 && ks < 30 && wave == 0 && lane == 0)                                 \
-            ((unsigned long long*)d.zero_page)[(1 << 19) + blockIdx.x * 128 + ks * 4 + (j)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define GPP_KSTAMP(j) do { } while (0)
-#endif
-    for (int ks = 0; ks < nk; ++ks) {
-        GPP_KSTAMP(0);
-        if (issued - ks - 1 >= PF - 1 && PF > 1)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * PER_STAGE) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        GPP_KSTAMP(1);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        GPP_KSTAMP(2);
-        if (issued < nk) {
-            if (d.reserved & 1) { ++issued; } else issue_next();      // bit 0 (diagnostic): skip the LDS-DMA
-        }
-        GPP_KSTAMP(3);
-        if (!(d.reserved & 2)) {                                       // bit 1 (diagnostic): skip LDS reads + MFMA
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                vec8 af[MF], bfr[NF];
-                load_frags(af, bfr, cbuf, kk);
-                mfma_all(af, bfr);
-            }
-        }
-        if (++cbuf == STAGES) cbuf = 0;
-    }
-    }
-    GPP_STAMP(2);
-    // ---- epilogue, straight from registers.  The MFMA was issued as D = W_tile * X_tile^T, so
-    // lane (fq = lane>>4, c = lane&15) of accumulator (i, j) holds output pixel i*16 + c and the four
-    // weight-tile rows fq*4 + 0..3 of N-tile j.  The packed weight rows are interleaved on the host
-    // (row 16h + 4q + r of every 32-row group = output channel 8q + 4h + r), hence tiles 2jj and
-    // 2jj+1 together give this lane EIGHT CONSECUTIVE output channels n = n0 + 32jj + 8fq + 0..7:
-    // one 16-byte store (two for float32 output), no LDS round trip.
-    constexpr int COLS = BN / WN;                        // output channels owned by this wave
-    static_assert(NF % 2 == 0, "N tiles come in interleaved pairs");
-    if (nsplit > 1) {
-        // raw float32 partial tile -> d.partial[split][mt*BM + row][nt*BN + col]
-        const int64_t rows_pad = (int64_t)d.partial_rows, npad = (int64_t)n_tiles * BN;
-        float* part = (float*)d.partial + ((int64_t)split * rows_pad + (int64_t)mt * BM) * npad + nt * BN;
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int lr = wm * (BM / WM) + i * 16 + frow;
-#pragma unroll
-            for (int jj = 0; jj < NF / 2; ++jj) {
-                float* dst = part + (int64_t)lr * npad + wn * COLS + jj * 32 + fq * 8;
-                *(f32x4*)dst = acc[i][2 * jj];
-                *(f32x4*)(dst + 4) = acc[i][2 * jj + 1];
-            }
-        }
-        return;
-    }
-    const scalar* res = (const scalar*)d.residual;
-    float bias_v[NF / 2][8];
-#pragma unroll
-    for (int jj = 0; jj < NF / 2; ++jj) {
-        const int n = n0 + wn * COLS + jj * 32 + fq * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias_v[jj][e] = (d.bias && n + e < d.C_out) ? d.bias[n + e] : 0.0f;
-    }
-    if constexpr (RESPRE) {
-        if (use_pre) {
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const int m = m0 + wm * (BM / WM) + i * 16 + frow;
-                if (m >= Mg) continue;
-#pragma unroll
-                for (int jj = 0; jj < NF / 2; ++jj) {
-                    const int n = n0 + wn * COLS + jj * 32 + fq * 8;
-                    if (n >= d.C_out) continue;
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
-                        v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
-                    }
-                    finish8_pre<DT>(d, v, n, ra_pre[i].obase, true, rpre[i][jj]);
-                }
-            }
-            GPP_STAMP(3);
-            GPP_STAMP(4);
-            return;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + frow;
-        if (m >= Mg) continue;
-        const RowAddr ra = row_addr(d, m, HoWo, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
-        const scalar* rrow = res ? res + ra.rbase : nullptr;
-#pragma unroll
-        for (int jj = 0; jj < NF / 2; ++jj) {
-            const int n = n0 + wn * COLS + jj * 32 + fq * 8;
-            if (n >= d.C_out) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
-                v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
-            }
-            finish8<DT>(d, v, n, ra.obase, rrow);
-        }
-    }
-    GPP_STAMP(3);
-#ifdef GPP_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    GPP_STAMP(4);
-}
-
-template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_conv_desc d)
-{
-    conv_igemm_body<DT, BM, BN, WM, WN, STAGES, PIPE>(d, blockIdx.x, gridDim.x);
-}
-
-// A layer whose C_out is an odd multiple of 128 (the fused tower inputs: 896 = 3 x 256 + 128) in ONE grid of two tile
-// shapes: workgroups [0, n0) cover the first C_out - 128 columns with 256 x 256 tiles (descriptor d0), workgroups
-// [split0, split0 + n1) the last 128 columns with the same kernel turned on its side, 512 x 128 tiles (descriptor d1 = the
-// same layer with its weight / bias / output pointers moved to that column block).  Every workgroup does the same amount
-// of matrix work, none of it on padding, and the hardware hands the second range out behind the first, into the CUs its
-// last partial round leaves idle: 1253 workgroups = 5 rounds instead of 1432 = 6 for the 896-column layer.
-template <int DT>
-__global__ __launch_bounds__(512, 2) void conv_igemm_dual_kernel(const gpp_conv_desc d0, const gpp_conv_desc d1, const int n0,
-                                                                 const int split0, const int n1)
-{
-    if ((int)blockIdx.x < split0) {
-        if ((int)blockIdx.x < n0) conv_igemm_body<DT, 256, 256, 2, 4, 2, true>(d0, blockIdx.x, n0);
-    } else {
-        conv_igemm_body<DT, 512, 128, 4, 2, 2, true>(d1, (int)blockIdx.x - split0, n1);
-    }
-}
-
-// Second pass of a split-K launch: sum the partial slabs in split order (deterministic), then the
-// same epilogue as the fused path.  One thread per (output row, 8 output channels).
-template <int DT>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const gpp_conv_desc d, int BM, int npad, int nsplit)
-{
-    using scalar = typename Elem<DT>::scalar;
-    const int n8 = (d.C_out + 7) / 8;
-    const int64_t total = (int64_t)d.partial_rows * n8;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int r = (int)(e / n8), n = (int)(e - (int64_t)r * n8) * 8;
-    const int mt = r / BM;
-    int tile_start = 0, H_out = 0, W_out = 0, H_res = 0, W_res = 0;
-    int64_t out_off = 0, out_bs = 0, res_off = 0, res_bs = 0;
-#pragma unroll
-    for (int q = 0; q < GPP_MAX_GROUPS; ++q) {
-        if (q < d.n_groups && mt >= d.groups[q].tile_start) {
-            tile_start = d.groups[q].tile_start;
-            H_out = d.groups[q].H_out; W_out = d.groups[q].W_out;
-            H_res = d.groups[q].H_res; W_res = d.groups[q].W_res;
-            out_off = d.groups[q].out_off; out_bs = d.groups[q].out_bstride;
-            res_off = d.groups[q].res_off; res_bs = d.groups[q].res_bstride;
-        }
-    }
-    const int HoWo = H_out * W_out;
-    const int m = r - tile_start * BM;
-    if (m >= d.batch * HoWo) return;
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = 0.0f;
-    const float* src = (const float*)d.partial + (int64_t)r * npad + n;
-    for (int s = 0; s < nsplit; ++s) {
-        const f32x4 a = *(const f32x4*)(src + (int64_t)s * d.partial_rows * npad);
-        const f32x4 b = *(const f32x4*)(src + (int64_t)s * d.partial_rows * npad + 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
-    }
-    if (d.bias) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (n + k < d.C_out) v[k] += d.bias[n + k];
-    }
-    const RowAddr ra = row_addr(d, m, HoWo, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
-    finish8<DT>(d, v, n, ra.obase, d.residual ? (const scalar*)d.residual + ra.rbase : nullptr);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused tail of a ResNet bottleneck: y = relu(W2 * relu(W1 (*) a + b1) + b2 + shortcut), i.e. the
-// 3x3 conv "branch2b" (CMID -> CMID, stride 1, pad 1) and the 1x1 conv "branch2c" (CMID -> 4*CMID,
-// + residual + ReLU) in one launch.  The BM x CMID tile of the intermediate never leaves the CU: it
-// goes accumulators -> (bias, ReLU, round to 16 bit exactly as the unfused layer would store it) ->
-// LDS in the A-operand layout, and is multiplied there by W2 in 128-wide output tiles.  Saves one
-// write + one read of the intermediate map (2 x 34.5 MB per res2 block at B = 8) on layers that are
-// HBM-bound; results are bit-identical to the two separate launches (same K order, same rounding).
-// d1 = descriptor of the 3x3 layer (its `out` is not written), d2 = descriptor of the 1x1 layer.
-//
-// NEXT = true additionally computes the FIRST layer of the following bottleneck, z = relu(W3 * y + b3) (1x1, 4*CMID ->
-// CMID, "branch2a" of the next identity block, descriptor d3): in phase 2 every wavefront then owns BM/4 full rows of
-// the y tile (4 x 1 layout), and after bias + shortcut + ReLU + rounding its registers hold exactly the MFMA activation
-// fragments of those rows (lane (q, c): pixel c, 8 consecutive channels 8q..8q+7 of a 32-channel slice), so y feeds
-// the next matrix product straight from registers while it is being stored; W3 fragments come from L2 one slice ahead.
-// Channel slices are consumed in ascending order, the order of the stand-alone layer's K-steps: z is bit-identical to
-// launching that layer on the stored y.  Saves that launch and its read of y (138 MB per res2 block at B = 8).
-template <int DT, int BM, int CMID, bool NEXT>
-__global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2, const gpp_conv_desc d3)
-{
-    using E = Elem<DT>;
-    using vec8 = typename E::vec8;
-    using scalar = typename E::scalar;
-    constexpr int WM = 2, WN = 2, NW = 4;
-    constexpr int P2M = NEXT ? 4 : 2, P2N = NEXT ? 1 : 2;                  // wavefront layout of phase 2
-    constexpr int MF = BM / WM / 16, NF1 = CMID / WN / 16;
-    constexpr int MF2 = BM / P2M / 16, NF2 = 128 / P2N / 16, COLS2 = 128 / P2N;   // phase 2: BM x 128 output tiles
-    constexpr int NZ = CMID / 16;                                          // phase 3: 16-channel tiles of z
-    static_assert(BM % (16 * P2M) == 0, "phase-2 wave tile");
-    constexpr int KC = CMID / 64;                                          // 64-channel chunks of the intermediate
-    constexpr int A_BYTES = BM * kRowBytes, B_BYTES = CMID * kRowBytes, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_IT = BM / 8 / NW, B_IT = CMID / 8 / NW, PER_STAGE = A_IT + B_IT;
-    constexpr int T_BYTES = KC * A_BYTES;                                  // intermediate tile, A-operand layout
-    constexpr int W2_IT = 128 / 8 / NW;                                    // LDS-DMA per wave per chunk of a W2 tile
-    static_assert(BM % 32 == 0 && (CMID == 64 || CMID == 128), "tile shape");
-    static_assert(T_BYTES + KC * 128 * kRowBytes <= 2 * STAGE, "phase-2 buffers alias the phase-1 ring");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int mt = xcd_remap(blockIdx.x, gridDim.x);
-    const gpp_conv_desc& d = d1;                                           // (GPP_STAMP reads d.reserved / d.zero_page)
-    (void)d;
-    GPP_STAMP(0);
-    const gpp_conv_group& G1 = d1.groups[0];
-    const gpp_conv_group& G2 = d2.groups[0];
-    const int H = G1.H_out, W = G1.W_out, HW = H * W;
-    const int Mg = d1.batch * HW;
-    const int m0 = mt * BM;
-
-    // ---- phase 1: 3x3 conv, the main loop of conv_igemm_kernel with BN = CMID
-    const int srow = lane >> 3;
-    const int gchunk = (lane & 7) ^ srow;
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d1.in, 0, d1.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d1.weight, 0, d1.weight_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d2.weight, 0, d2.weight_bytes, 0x00020000);
-    int a_base[A_IT], a_mask[A_IT], a_voff[A_IT];
-    const int pitch2 = d1.in_pitch * 2;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + (wave * A_IT + i) * 8 + srow;
-        a_mask[i] = 0;
-        a_base[i] = 0;
-        if (m < Mg) {
-            const int b = m / HW, p = m - b * HW;
-            const int oy = p / W, ox = p - oy * W;
-            const int iy0 = oy - 1, ix0 = ox - 1;
-            int mask = 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) mask |= (((unsigned)(iy0 + k) < (unsigned)H) << k) | (((unsigned)(ix0 + k) < (unsigned)W) << (8 + k));
-            a_mask[i] = mask;
-            a_base[i] = (int)((G1.in_off + (int64_t)b * G1.in_bstride) * 2) + gchunk * 16 + (iy0 * W + ix0) * pitch2;
-        }
-    }
-    constexpr int Ktot1 = 9 * CMID;
-    int w_voff[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) w_voff[i] = ((wave * B_IT + i) * 8 + srow) * Ktot1 * 2 + gchunk * 16;
-    auto set_tap = [&](int kh, int kw) {
-        const int delta = (kh * W + kw) * pitch2;
-        const int need = (1 << kh) | (1 << (8 + kw));
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) a_voff[i] = ((a_mask[i] & need) == need) ? a_base[i] + delta : kOutOfRange;
-    };
-    const int frow = lane & 15, fq = lane >> 4;
-    const int wm2 = wave / P2N, wn2 = wave % P2N;
-    int a_rd[2], b1_rd[2], a_rd2[2], b2_rd[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int sw = ((kk * 4 + fq) ^ (frow & 7)) << 4;
-        a_rd[kk] = (wm * (BM / WM) + frow) * kRowBytes + sw;
-        b1_rd[kk] = A_BYTES + (wn * (CMID / WN) + frow) * kRowBytes + sw;
-        a_rd2[kk] = (wm2 * (BM / P2M) + frow) * kRowBytes + sw;
-        b2_rd[kk] = T_BYTES + (wn2 * COLS2 + frow) * kRowBytes + sw;
-    }
-    f32x4 acc1[MF][NF1];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF1; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int nk = 9 * KC;
-    int cc = 0, kw = 0, kh = 0, issued = 0, ibuf = 0;
-    set_tap(0, 0);
-    auto issue_next = [&]() {
-        unsigned char* sa = smem + ibuf * STAGE + wave * A_IT * 8 * kRowBytes;
-        unsigned char* sb = smem + ibuf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) glds16(in_rsrc, a_voff[i], cc * kRowBytes, sa + i * 8 * kRowBytes);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(w1_rsrc, w_voff[i], issued * kRowBytes, sb + i * 8 * kRowBytes);
-        if (++kw == 3) {
-            kw = 0;
-            if (++kh == 3) { kh = 0; ++cc; }
-        }
-        set_tap(kh, kw);
-        ++issued;
-        ibuf ^= 1;
-    };
-    // The shortcut rows of output tile t (phase 2) are fetched into registers long before they are used: tile 0's right
-    // here, in flight underneath the whole 3x3 phase; tile t+1's under tile t's epilogue stores.  When the epilogue
-    // issued them itself (load -> wait -> add -> store, twice per workgroup) it was the longest phase of this HBM-bound
-    // kernel: 20.7 of 29.8 us per workgroup at C = 64.
-    RowAddr ra[MF2];
-#pragma unroll
-    for (int i = 0; i < MF2; ++i) {
-        const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
-        ra[i] = row_addr(d2, m < Mg ? m : 0, HW, W, H, G2.H_res, G2.W_res, G2.out_off, G2.out_bstride, G2.res_off, G2.res_bstride);
-    }
-    const scalar* res = (const scalar*)d2.residual;
-    vec8 rpre[MF2][NF2 / 2];
-    auto prefetch_res = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < MF2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < NF2 / 2; ++jj) {
-                const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
-                rpre[i][jj] = *(const vec8*)(res + ra[i].rbase + n);       // rows past the end were clamped to row 0: a valid address
-            }
-    };
-    if (res) prefetch_res(0);
-    issue_next();
-    for (int ks = 0; ks < nk; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (issued < nk) issue_next();
-        const unsigned char* sbase = smem + (ks & 1) * STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            vec8 af[MF], bfr[NF1];
-#pragma unroll
-            for (int i = 0; i < MF; ++i) af[i] = *(const vec8*)(sbase + a_rd[kk] + i * 16 * kRowBytes);
-#pragma unroll
-            for (int j = 0; j < NF1; ++j) bfr[j] = *(const vec8*)(sbase + b1_rd[kk] + j * 16 * kRowBytes);
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < NF1; ++j) acc1[i][j] = E::mfma(bfr[j], af[i], acc1[i][j]);
-        }
-    }
-
-    GPP_STAMP(1);
-    // ---- hand-over: everyone is done with the ring; W2 tile 0 starts streaming in while the
-    // intermediate tile is written (bias, ReLU, rounded to the storage type) in A-operand layout
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int w2_voff[W2_IT];
-#pragma unroll
-    for (int i = 0; i < W2_IT; ++i) w2_voff[i] = ((wave * W2_IT + i) * 8 + srow) * CMID * 2 + gchunk * 16;
-    auto stage_w2 = [&](int t) {
-        // rows t*128 .. t*128+127 of the packed 1x1 weights, KC chunks of 128 bytes each
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-            for (int i = 0; i < W2_IT; ++i)
-                glds16(w2_rsrc, w2_voff[i], t * 128 * CMID * 2 + kc * kRowBytes,
-                       smem + T_BYTES + kc * 128 * kRowBytes + (wave * W2_IT + i) * 8 * kRowBytes);
-    };
-    stage_w2(0);
-    {
-        constexpr int COLS1 = CMID / WN;
-#pragma unroll
-        for (int jj = 0; jj < NF1 / 2; ++jj) {
-            const int n = wn * COLS1 + jj * 32 + fq * 8;              // 8 consecutive intermediate channels
-            float bias_v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias_v[e] = d1.bias ? d1.bias[n + e] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const int r = wm * (BM / WM) + i * 16 + frow;
-                vec8 ov;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float lo = acc1[i][2 * jj][e] + bias_v[e], hi = acc1[i][2 * jj + 1][e] + bias_v[4 + e];
-                    if (d1.relu) { lo = fmaxf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }
-                    ov[e] = (scalar)lo;
-                    ov[4 + e] = (scalar)hi;
-                }
-                const int chunk = (n & 63) >> 3;
-                *(vec8*)(smem + (n >> 6) * A_BYTES + r * kRowBytes + ((chunk ^ (r & 7)) << 4)) = ov;
-            }
-        }
-    }
-
-    GPP_STAMP(2);
-    // ---- phase 2: y tile = T (BM x CMID) * W2^T, 128 output channels at a time
-    const int n2_tiles = d2.C_out / 128;
-    // phase 3 state (NEXT): z accumulators and the W3 fragments of the current 32-channel slice (lane (q, r): stored row
-    // 16*j + r of W3, bytes of channels slice*32 + 8q .. 8q+7), fetched from L2 one slice ahead
-    f32x4 zacc[NEXT ? MF2 : 1][NEXT ? NZ : 1];
-    vec8 w3f[NEXT ? NZ : 1];
-    const scalar* w3 = (const scalar*)d3.weight;
-    const int K3 = d3.C_in;
-    auto load_w3 = [&](vec8 (&dst)[NEXT ? NZ : 1], int slice) {
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) dst[j] = *(const vec8*)(w3 + (int64_t)(j * 16 + frow) * K3 + slice * 32 + fq * 8);
-    };
-    if constexpr (NEXT) {
-#pragma unroll
-        for (int i = 0; i < MF2; ++i)
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        load_w3(w3f, 0);
-    }
-    for (int t = 0; t < n2_tiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                  // W2 tile t (and, for t = 0, T) is in LDS
-        asm volatile("" ::: "memory");
-        f32x4 acc2[MF2][NF2];
-#pragma unroll
-        for (int i = 0; i < MF2; ++i)
-#pragma unroll
-            for (int j = 0; j < NF2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                vec8 af[MF2], bfr[NF2];
-#pragma unroll
-                for (int i = 0; i < MF2; ++i) af[i] = *(const vec8*)(smem + kc * A_BYTES + a_rd2[kk] + i * 16 * kRowBytes);
-#pragma unroll
-                for (int j = 0; j < NF2; ++j) bfr[j] = *(const vec8*)(smem + kc * 128 * kRowBytes + b2_rd[kk] + j * 16 * kRowBytes);
-#pragma unroll
-                for (int i = 0; i < MF2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NF2; ++j) acc2[i][j] = E::mfma(bfr[j], af[i], acc2[i][j]);
-            }
-        if (t + 1 < n2_tiles) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // everyone has read W2 tile t
-            asm volatile("" ::: "memory");
-            stage_w2(t + 1);                                           // streams in under the epilogue below
-        }
-        // bias + shortcut + ReLU into the accumulators (this consumes rpre), then refill rpre for the next tile, then store
-        float outv[MF2][NF2 / 2][8];
-#pragma unroll
-        for (int jj = 0; jj < NF2 / 2; ++jj) {
-            const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
-            float bias_v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias_v[e] = d2.bias ? d2.bias[n + e] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < MF2; ++i) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    outv[i][jj][e] = acc2[i][2 * jj][e] + bias_v[e];
-                    outv[i][jj][4 + e] = acc2[i][2 * jj + 1][e] + bias_v[4 + e];
-                }
-                if (res) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) outv[i][jj][e] += (float)rpre[i][jj][e];
-                }
-                if (NEXT && d2.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) outv[i][jj][e] = fmaxf(outv[i][jj][e], 0.0f);
-                }
-            }
-        }
-        if (res && t + 1 < n2_tiles) prefetch_res(t + 1);
-        if constexpr (NEXT) {
-            // phase 3: the rounded y values are the activation fragments of the next 1x1 layer
-#pragma unroll
-            for (int jj = 0; jj < NF2 / 2; ++jj) {
-                const int slice = t * (NF2 / 2) + jj;
-                vec8 w3n[NZ];
-                if (slice + 1 < n2_tiles * (NF2 / 2)) load_w3(w3n, slice + 1);
-#pragma unroll
-                for (int i = 0; i < MF2; ++i) {
-                    vec8 yf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) yf[e] = (scalar)outv[i][jj][e];
-#pragma unroll
-                    for (int j = 0; j < NZ; ++j) zacc[i][j] = E::mfma(w3f[j], yf, zacc[i][j]);
-                }
-#pragma unroll
-                for (int j = 0; j < NZ; ++j) w3f[j] = w3n[j];
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < NF2 / 2; ++jj) {
-            const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
-#pragma unroll
-            for (int i = 0; i < MF2; ++i) {
-                const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
-                if (m >= Mg) continue;
-                finish8_pre<DT>(d2, outv[i][jj], n, ra[i].obase, false, rpre[i][jj]);
-            }
-        }
-    }
-    if constexpr (NEXT) {
-        // z = relu(zacc + b3): pairs of 16-row W3 tiles give every lane 8 consecutive output channels, as everywhere
-        const gpp_conv_group& G3 = d3.groups[0];
-#pragma unroll
-        for (int q = 0; q < NZ / 2; ++q) {
-            const int n3 = q * 32 + fq * 8;
-            float bias_v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias_v[e] = d3.bias ? d3.bias[n3 + e] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < MF2; ++i) {
-                const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
-                if (m >= Mg) continue;
-                const int b = m / HW, p = m - b * HW;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = zacc[i][2 * q][e] + bias_v[e];
-                    v[4 + e] = zacc[i][2 * q + 1][e] + bias_v[4 + e];
-                }
-                finish8_pre<DT>(d3, v, n3, G3.out_off + (int64_t)b * G3.out_bstride + (int64_t)p * d3.out_pitch, false, w3f[0]);
-            }
-        }
-    }
-    GPP_STAMP(3);
-#ifdef GPP_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    GPP_STAMP(4);
-}
-
-// Fill in what the kernel needs beyond the caller's fields (buffer extents, first tile of every group); returns the
-// number of M tiles or a negative error.
-template <int BM, int BN>
-int prepare(gpp_conv_desc& d)
-{
-    if (d.weight_rows < ((d.C_out + BN - 1) / BN) * BN) return GPP_ERR_BAD_ARG;
-    int64_t in_elems = 0;
-    for (int g = 0; g < d.n_groups; ++g) {
-        const gpp_conv_group& G = d.groups[g];
-        const int64_t end = G.in_off + (int64_t)(d.batch - 1) * G.in_bstride + ((int64_t)G.H_in * G.W_in - 1) * d.in_pitch + d.C_in;
-        if (G.in_off < 0 || G.in_bstride < 0) return GPP_ERR_BAD_ARG;
-        in_elems = end > in_elems ? end : in_elems;
-    }
-    const int64_t w_bytes = (int64_t)d.weight_rows * d.KH * d.KW * d.C_in * 2;
-    if (in_elems * 2 >= (1LL << 31) || w_bytes >= (1LL << 31)) return GPP_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-    d.in_bytes = (int32_t)(in_elems * 2);
-    d.weight_bytes = (int32_t)w_bytes;
-    int tiles = 0;
-    for (int g = 0; g < d.n_groups; ++g) {
-        d.groups[g].tile_start = tiles;
-        tiles += (d.batch * d.groups[g].H_out * d.groups[g].W_out + BM - 1) / BM;
-    }
-    d.partial_rows = tiles * BM;
-    return tiles;
-}
-
-// One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.
-template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
-int launch(gpp_conv_desc& d, hipStream_t st)
-{
-    constexpr int lds = STAGES * (BM + BN) * kRowBytes;
-    static bool configured = false;
-    auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES, PIPE>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
-    const int tiles = prepare<BM, BN>(d);
-    if (tiles < 0) return tiles;
-    const int n_tiles = (d.C_out + BN - 1) / BN;
-    // split-K when the tile grid leaves most of the 256 CUs idle and K is deep: every split keeps
-    // >= 8 K-steps; partial slabs [split][tiles*BM][n_tiles*BN] float32 must fit the workspace
-    const int nk = d.KH * d.KW * (d.C_in / 64);
-    int nsplit = 1;
-    if (d.partial && d.split_k != 1) {
-        const int blocks = tiles * n_tiles;
-        int want = d.split_k > 1 ? d.split_k : (blocks < 192 ? (384 + blocks - 1) / blocks : 1);
-        while (want > 1 && nk / want < (d.split_k > 1 ? 4 : 8)) --want;      // explicit requests (autotune) may go down to 4 K-steps per split
-        const int64_t slab = (int64_t)tiles * BM * n_tiles * BN * 4;
-        while (want > 1 && slab * want > (int64_t)d.partial_bytes) --want;
-        nsplit = want < 1 ? 1 : want;
-    }
-    // a layer with fewer K-steps than ring slots (1x1 convs with C_in = 64) only touches the first slots:
-    // declaring just those lets more workgroups share a CU, which is what the HBM-bound layers need
-    const int steps = (nk + nsplit - 1) / nsplit;
-    const int lds_used = (steps < STAGES ? steps : STAGES) * (BM + BN) * kRowBytes;
-    kernel<<<dim3((unsigned)(tiles * n_tiles), (unsigned)nsplit), dim3(64 * WM * WN), lds_used, st>>>(d);
-    if (nsplit > 1) {
-        const int64_t total = (int64_t)d.partial_rows * ((d.C_out + 7) / 8);
-        splitk_reduce_kernel<DT><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(d, BM, n_tiles * BN, nsplit);
-    }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? GPP_OK : (int)e;
-}
-
-// conv_igemm_dual_kernel: C_out = 256 k + 128.  The caller's descriptor is split into the two column blocks here.
-template <int DT>
-int launch_dual(const gpp_conv_desc& d, hipStream_t st)
-{
-    if (d.C_out < 384 || d.C_out % 256 != 128 || d.KH * d.KW * (d.C_in / 64) < 2) return GPP_ERR_UNSUPPORTED;
-    constexpr int lds = 2 * (512 + 128) * kRowBytes;          // 160 KB: the larger of the two bodies
-    static bool configured = false;
-    auto kernel = conv_igemm_dual_kernel<DT>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
-    const int head = d.C_out - 128;                           // columns of the 256-wide part: a multiple of 256
-    gpp_conv_desc d0 = d, d1 = d;
-    d0.C_out = head;
-    d1.C_out = 128;
-    d1.weight = (const char*)d.weight + (int64_t)head * d.KH * d.KW * d.C_in * 2;
-    d1.weight_rows = d.weight_rows - head;
-    if (d.bias) d1.bias = d.bias + head;
-    for (int g = 0; g < d.n_groups; ++g) {
-        d1.groups[g].out_off += head;
-        d1.groups[g].res_off += head;
-    }
-    const int t0 = prepare<256, 256>(d0), t1 = prepare<512, 128>(d1);
-    if (t0 < 0) return t0;
-    if (t1 < 0) return t1;
-    const int n0 = t0 * (head / 256), n1 = t1;
-    const int split0 = (n0 + 7) / 8 * 8;                      // keeps workgroup index % 8 = XCD for the second range's remap
-    kernel<<<dim3((unsigned)(split0 + n1)), dim3(512), lds, st>>>(d0, d1, n0, split0, n1);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? GPP_OK : (int)e;
-}
-
-template <int DT>
-int dispatch(gpp_conv_desc& d, hipStream_t st)
-{
-    switch (d.tile_hint) {               // explicit choices (BM*1000 + BN, or the legacy codes): what the host-side autotuner hands in
-        case 64:
-        case 128064: return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
-        case 64064: return launch<DT, 64, 64, 2, 2, 2, false>(d, st);
-        case 96064: return launch<DT, 96, 64, 2, 2, 2, false>(d, st);
-        case 160064: return launch<DT, 160, 64, 2, 2, 2, false>(d, st);
-        case 192064: return launch<DT, 192, 64, 2, 2, 2, false>(d, st);
-        case 64128: return launch<DT, 64, 128, 2, 2, 2, false>(d, st);
-        case 96128: return launch<DT, 96, 128, 2, 2, 2, false>(d, st);
-        case 128:
-        case 128128: return (d.reserved & 4) ? launch<DT, 128, 128, 2, 2, 2, true>(d, st) : launch<DT, 128, 128, 2, 2, 2, false>(d, st);
-        case 160128: return launch<DT, 160, 128, 2, 2, 2, false>(d, st);
-        case 192128: return launch<DT, 192, 128, 2, 2, 2, false>(d, st);
-        case 224128: return launch<DT, 224, 128, 2, 2, 2, false>(d, st);
-        case 256: return launch<DT, 256, 128, 4, 2, 3, false>(d, st);          // 3-deep ring, experiments only
-        case 1128128: return launch<DT, 128, 128, 2, 2, 2, true>(d, st);        // 1000000 + ...: the pipelined main loop
-        case 1192128: return launch<DT, 192, 128, 2, 2, 2, true>(d, st);
-        case 1128256: return launch<DT, 128, 256, 2, 4, 2, true>(d, st);
-        case 1192256: return launch<DT, 192, 256, 2, 4, 2, true>(d, st);
-        // N-remainder tiles (4 x 1 wavefronts, wave tile BM/4 x 160): layers whose C_out is far from a multiple of 128
-        // (regression outputs: 144 -> 160 instead of 256 columns; measured 200 -> 162 us).  96-wide tiles and 3/4-deep
-        // LDS rings on the small tiles were measured too and lost everywhere (fewer workgroups per CU).
-        case 128160: return launch<DT, 128, 160, 4, 1, 2, false>(d, st);
-        case 192160: return launch<DT, 192, 160, 4, 1, 2, false>(d, st);
-        case 1192160: return launch<DT, 192, 160, 4, 1, 2, true>(d, st);
-        case 2256256: return launch_dual<DT>(d, st);            // 256 x 256 tiles + 512 x 128 tiles for the last 128 columns, one grid
-        case 512:
-        case 256256: return (d.reserved & 8) ? launch<DT, 256, 256, 2, 4, 2, false>(d, st) : launch<DT, 256, 256, 2, 4, 2, true>(d, st);
-        case 0: break;
-        default: return GPP_ERR_BAD_ARG;
-    }
-    // ---- default heuristic (tile_hint == 0)
-    if (d.C_out <= 64 || (d.C_out % 128 != 0 && d.C_out % 128 <= 64)) return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
-    // 256x256 tile (8 wavefronts, 1 workgroup / CU) halves the L2 -> LDS traffic per FLOP; it pays
-    // when there are enough tiles for two rounds over the 256 CUs and enough K-steps to amortise
-    // its longer prologue/epilogue
-    int64_t rows = 0;
-    for (int g = 0; g < d.n_groups; ++g) rows += (int64_t)d.batch * d.groups[g].H_out * d.groups[g].W_out;
-    const int nk = d.KH * d.KW * (d.C_in / 64);
-    const int n256 = (d.C_out + 255) / 256;
-    const int64_t big_blocks = ((rows + 255) / 256) * n256;
-    const bool n_fits = d.C_out >= 256 && n256 * 256 * 7 <= d.C_out * 8;      // at most 1/8 of the N tiles is padding
-    if (n_fits && big_blocks >= 512 && nk >= 8) return launch<DT, 256, 256, 2, 4, 2, true>(d, st);
-    return launch<DT, 128, 128, 2, 2, 2, false>(d, st);
-}
+inline int elem_size(int dtype) { return dtype == GPP_F32 ? 4 : 2; }
 
 int validate(const gpp_conv_desc& d)
 {
     if (!d.in || !d.weight || !d.out) return GPP_ERR_BAD_ARG;
-    if (d.dtype != GPP_BF16 && d.dtype != GPP_F16) return GPP_ERR_UNSUPPORTED;
+    if (d.dtype != GPP_BF16 && d.dtype != GPP_F16 && d.dtype != GPP_F32) return GPP_ERR_UNSUPPORTED;
+    const int esz = elem_size(d.dtype), ck = 128 / esz, va = 16 / esz;     // channels per K-step, elements per 16 bytes
     if (d.batch <= 0 || d.C_in <= 0 || d.C_out <= 0 || d.KH <= 0 || d.KW <= 0) return GPP_ERR_BAD_ARG;
     if (d.KH > 8 || d.KW > 8) return GPP_ERR_UNSUPPORTED;           // tap validity masks are 8 + 8 bits
-    if (d.C_in % 64 != 0 || d.C_out % 4 != 0) return GPP_ERR_UNSUPPORTED;
+    if (d.C_in % ck != 0 || d.C_out % 4 != 0) return GPP_ERR_UNSUPPORTED;
     if (d.stride != 1 && d.stride != 2) return GPP_ERR_UNSUPPORTED;
     if (d.n_groups < 1 || d.n_groups > GPP_MAX_GROUPS) return GPP_ERR_BAD_ARG;
-    if (d.in_pitch < d.C_in || d.in_pitch % 8 != 0) return GPP_ERR_ALIGN;
-    if (d.out_pitch < d.C_out || d.out_pitch % (d.out_f32 ? 4 : 8) != 0) return GPP_ERR_ALIGN;
-    if (d.residual && (d.res_pitch < d.C_out || d.res_pitch % 8 != 0)) return GPP_ERR_ALIGN;
+    if (d.split_k < 0) return GPP_ERR_BAD_ARG;
+#ifndef GPP_STAMPS
+    if (d.reserved != 0) return GPP_ERR_BAD_ARG;                    // diagnostic switches exist in -DGPP_STAMPS builds only
+#endif
+    const int oa = (d.out_f32 || d.dtype == GPP_F32) ? 4 : 8;        // output elements per 16 bytes
+    if (d.in_pitch < d.C_in || d.in_pitch % va != 0) return GPP_ERR_ALIGN;
+    if (d.out_pitch < d.C_out || d.out_pitch % oa != 0) return GPP_ERR_ALIGN;
+    if (d.residual && (d.res_pitch < d.C_out || d.res_pitch % va != 0)) return GPP_ERR_ALIGN;
     if (((uintptr_t)d.in | (uintptr_t)d.weight | (uintptr_t)d.out | (uintptr_t)d.zero_page | (uintptr_t)d.residual |
-         (uintptr_t)d.bias) & 15)
+         (uintptr_t)d.bias | (uintptr_t)d.partial) & 15)
         return GPP_ERR_ALIGN;
     for (int g = 0; g < d.n_groups; ++g) {
         const gpp_conv_group& G = d.groups[g];
         if (G.H_in <= 0 || G.W_in <= 0 || G.H_out <= 0 || G.W_out <= 0) return GPP_ERR_BAD_ARG;
-        if ((G.in_off | G.in_bstride | G.out_off | G.out_bstride) % (d.out_f32 ? 4 : 8) != 0) return GPP_ERR_ALIGN;
-        if ((G.in_off | G.in_bstride) % 8 != 0) return GPP_ERR_ALIGN;
-        if (d.residual && ((G.res_off | G.res_bstride) % 8 != 0 || G.H_res <= 0 || G.W_res <= 0)) return GPP_ERR_ALIGN;
+        if ((G.out_off | G.out_bstride) % oa != 0) return GPP_ERR_ALIGN;
+        if ((G.in_off | G.in_bstride) % va != 0) return GPP_ERR_ALIGN;
+        if (d.residual && ((G.res_off | G.res_bstride) % va != 0 || G.H_res <= 0 || G.W_res <= 0)) return GPP_ERR_ALIGN;
         if ((int64_t)d.batch * G.H_out * G.W_out >= (1LL << 31)) return GPP_ERR_UNSUPPORTED;
     }
     return GPP_OK;
 }
 
-template <int DT, int BM, int CMID, bool NEXT>
-int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, hipStream_t st)
+// Split-K factor of a layer as a function of the LAYER ALONE -- kernel size, channels, output pixels PER IMAGE -- never of
+// the batch size, the tile or a timing: the float32 summation order of an output element, and with it every bit of the
+// result, is then the same whether an image is computed alone, in a batch of 64 or on another rank.
+// Deep-K layers whose per-image tile grid is tiny (res5 branch2b, P5, P6, P7) are split; everything else is not.
+int split_rule(const gpp_conv_desc& d)
 {
-    constexpr int lds = 2 * (BM + CMID) * kRowBytes;
-    static bool configured = false;
-    auto kernel = bottleneck_tail_kernel<DT, BM, CMID, NEXT>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
-    const gpp_conv_group& G = d1.groups[0];
-    const int64_t in_elems = G.in_off + (int64_t)(d1.batch - 1) * G.in_bstride + ((int64_t)G.H_in * G.W_in - 1) * d1.in_pitch + d1.C_in;
-    const int64_t w1_bytes = (int64_t)d1.weight_rows * 9 * CMID * 2, w2_bytes = (int64_t)d2.weight_rows * CMID * 2;
-    if (G.in_off < 0 || G.in_bstride < 0 || in_elems * 2 >= (1LL << 31) || w1_bytes >= (1LL << 31) || w2_bytes >= (1LL << 31))
-        return GPP_ERR_UNSUPPORTED;
-    d1.in_bytes = (int32_t)(in_elems * 2);
-    d1.weight_bytes = (int32_t)w1_bytes;
-    d2.weight_bytes = (int32_t)w2_bytes;
-    const int64_t rows = (int64_t)d1.batch * G.H_out * G.W_out;
-    kernel<<<dim3((unsigned)((rows + BM - 1) / BM)), dim3(256), lds, st>>>(d1, d2, d3);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? GPP_OK : (int)e;
+    if (!d.partial) return 1;
+    int64_t pix = 0;
+    for (int g = 0; g < d.n_groups; ++g) pix += (int64_t)d.groups[g].H_out * d.groups[g].W_out;
+    const int64_t tiles_per_image = ((pix + 127) / 128) * ((d.C_out + 127) / 128);
+    const int64_t kdepth = (int64_t)d.KH * d.KW * d.C_in;
+    if (tiles_per_image > 24 || kdepth < 3072) return 1;
+    int split = (int)((kdepth + 768) / 1536);
+    return split < 1 ? 1 : (split > 8 ? 8 : split);
 }
 
-template <int DT>
-int dispatch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc* d3, int tile_rows, hipStream_t st)
+int dispatch_any(gpp_conv_desc& d, hipStream_t st)
 {
-    const bool c64 = d1.C_in == 64;
-    if (d3) {                            // + first layer of the next block: phase 2 is 4 x 1 wavefronts, BM / 4 rows each
-        switch (tile_rows) {
-            case 64: return c64 ? launch_tail<DT, 64, 64, true>(d1, d2, *d3, st) : launch_tail<DT, 64, 128, true>(d1, d2, *d3, st);
-            case 0: return c64 ? launch_tail<DT, 128, 64, true>(d1, d2, *d3, st) : launch_tail<DT, 64, 128, true>(d1, d2, *d3, st);
-            case 128: return c64 ? launch_tail<DT, 128, 64, true>(d1, d2, *d3, st) : GPP_ERR_UNSUPPORTED;   // C = 128: 64 rows only (registers)
-            default: return GPP_ERR_BAD_ARG;
-        }
-    }
-    switch (tile_rows) {
-        case 96: return c64 ? launch_tail<DT, 96, 64, false>(d1, d2, d2, st) : launch_tail<DT, 96, 128, false>(d1, d2, d2, st);
-        case 0:
-        case 128: return c64 ? launch_tail<DT, 128, 64, false>(d1, d2, d2, st) : launch_tail<DT, 128, 128, false>(d1, d2, d2, st);
-        case 160: return c64 ? launch_tail<DT, 160, 64, false>(d1, d2, d2, st) : launch_tail<DT, 160, 128, false>(d1, d2, d2, st);
-        default: return GPP_ERR_BAD_ARG;
+    if (d.split_k == 0) d.split_k = split_rule(d);
+    switch (d.dtype) {
+        case GPP_BF16: return gpp_conv_dispatch_bf16(d, st);
+        case GPP_F16: return gpp_conv_dispatch_f16(d, st);
+        default: return gpp_conv_dispatch_f32(d, st);
     }
 }
 
@@ -1211,6 +82,7 @@ int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const
     if (rc != GPP_OK) return rc;
     const gpp_conv_group &G1 = d1.groups[0], &G2 = d2.groups[0];
     // the pair this kernel fuses: 3x3 / stride 1 / pad 1 / C -> C (C = 64 or 128) feeding 1x1 / stride 1 / C -> multiple of 128
+    if (d1.dtype == GPP_F32) return GPP_ERR_UNSUPPORTED;            // 16-bit storage types only
     if (d1.dtype != d2.dtype || d1.n_groups != 1 || d2.n_groups != 1 || d1.batch != d2.batch) return GPP_ERR_UNSUPPORTED;
     if (d1.KH != 3 || d1.KW != 3 || d1.stride != 1 || d1.pad_top != 1 || d1.pad_left != 1 || d1.residual || d1.out_f32) return GPP_ERR_UNSUPPORTED;
     if (d1.C_in != d1.C_out || (d1.C_in != 64 && d1.C_in != 128) || d1.weight_rows < d1.C_out) return GPP_ERR_UNSUPPORTED;
@@ -1232,8 +104,8 @@ int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const
         if (d3.in != d2.out || G3.in_off != G2.out_off || G3.in_bstride != G2.out_bstride || d3.in_pitch != d2.out_pitch) return GPP_ERR_BAD_ARG;
         if (G3.H_in != G2.H_out || G3.W_in != G2.W_out || G3.H_out != G2.H_out || G3.W_out != G2.W_out) return GPP_ERR_BAD_ARG;
     }
-    return d1.dtype == GPP_BF16 ? dispatch_tail<GPP_BF16>(d1, d2, next1x1 ? &d3 : nullptr, tile_rows, st)
-                                : dispatch_tail<GPP_F16>(d1, d2, next1x1 ? &d3 : nullptr, tile_rows, st);
+    return d1.dtype == GPP_BF16 ? gpp_tail_dispatch_bf16(d1, d2, next1x1 ? &d3 : nullptr, tile_rows, st)
+                                : gpp_tail_dispatch_f16(d1, d2, next1x1 ? &d3 : nullptr, tile_rows, st);
 }
 
 }  // namespace
@@ -1261,42 +133,70 @@ extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)
     return GPP_OK;
 }
 
+extern "C" int gpp_conv2d_split_rule(const gpp_conv_desc* host_desc, int* split_k)
+{
+    if (!host_desc || !split_k) return GPP_ERR_BAD_ARG;
+    gpp_conv_desc d = *host_desc;
+    int rc = validate(d);
+    if (rc != GPP_OK) return rc;
+    *split_k = d.split_k > 0 ? d.split_k : split_rule(d);
+    return GPP_OK;
+}
+
+extern "C" int gpp_conv2d_workspace_bytes(const gpp_conv_desc* host_desc, size_t* bytes)
+{
+    if (!host_desc || !bytes) return GPP_ERR_BAD_ARG;
+    gpp_conv_desc d = *host_desc;
+    char probe[16] __attribute__((aligned(16)));
+    if (!d.partial) { d.partial = probe; d.partial_bytes = 0; }     // the rule is asked "what if a workspace existed"
+    int rc = validate(d);
+    if (rc != GPP_OK) return rc;
+    const int split = d.split_k > 0 ? d.split_k : split_rule(d);
+    *bytes = 0;
+    if (split <= 1) return GPP_OK;
+    // partial slabs [split][M tiles * BM][N tiles * BN] float32 for the largest block tile (224 rows, 256 columns)
+    int64_t rows = 0;
+    for (int g = 0; g < d.n_groups; ++g) rows += (int64_t)d.batch * d.groups[g].H_out * d.groups[g].W_out + 256;
+    const int64_t npad = (d.C_out + 255) / 256 * 256;
+    *bytes = (size_t)(split * rows * npad * 4);
+    return GPP_OK;
+}
+
 extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 {
     if (!host_desc) return GPP_ERR_BAD_ARG;
     gpp_conv_desc d = *host_desc;
     int rc = validate(d);
     if (rc != GPP_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    return d.dtype == GPP_BF16 ? dispatch<GPP_BF16>(d, st) : dispatch<GPP_F16>(d, st);
+    return dispatch_any(d, (hipStream_t)stream);
 }
 
-// Pick the fastest tile / split-K configuration for one layer by timing the candidates on the
-// device (the layer is idempotent: it only rewrites its own output).  The tile-count arithmetic
-// (how many workgroups land on 256 CUs, in how many rounds) decides most mid-sized layers and is
-// not worth modelling: measure.  Writes the winner into desc->tile_hint / desc->split_k.
+// Pick the fastest block tile for one layer by timing the candidates on the device (the layer is idempotent: it only
+// rewrites its own output).  The tile-count arithmetic (how many workgroups land on 256 CUs, in how many rounds) decides
+// most mid-sized layers and is not worth modelling: measure.  Writes the winner into desc->tile_hint.  The tile never
+// changes a result (same K order per output element); split-K would, and is therefore NOT tuned: desc->split_k is used as
+// given (0 = gpp_conv2d_split_rule).
 extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* best_us)
 {
     if (!desc || iters < 1) return GPP_ERR_BAD_ARG;
     static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                                  1128128, 1192128, 1128256, 1192256, 256256,
                                  128160, 192160, 1192160, 2256256};
-    static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);
     if (e != hipSuccess) return (int)e;
     e = hipEventCreate(&e1);
     if (e != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
-    const int tile_in = desc->tile_hint, split_in = desc->split_k;
-    const int nk = desc->KH * desc->KW * (desc->C_in / 64);
+    const int tile_in = desc->tile_hint;
+    const int ck = 128 / elem_size(desc->dtype);
+    const int nk = desc->KH * desc->KW * (desc->C_in / ck);
     int64_t rows = 0;
     for (int g = 0; g < desc->n_groups; ++g) rows += (int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out;
     float best = 1e30f;
-    int best_tile = tile_in, best_split = split_in, rc = GPP_OK;
-    auto time_one = [&](int tile, int split, float* us) -> int {
+    int best_tile = tile_in, rc = GPP_OK;
+    auto time_one = [&](int tile, float* us) -> int {
         desc->tile_hint = tile;
-        desc->split_k = split;
         int r = gpp_conv2d_igemm(desc, stream);                      // warm-up (and validity of this choice)
         if (r != GPP_OK) return r;
         float t_best = 1e30f;
@@ -1314,29 +214,21 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         return GPP_OK;
     };
     for (int tile : kTiles) {
-        const int bn = tile % 1000 ? tile % 1000 : 128, bm = tile ? (tile / 1000) % 1000 : 128;
+        const int bn = tile % 1000 ? tile % 1000 : 128;
         if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
         if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) continue;
-        if (tile > 1000000 && nk < 4) continue;                      // the pipelined loop needs a few K-steps to pay
+        if (tile > 1000000 && (nk < 4 || desc->dtype == GPP_F32)) continue;   // the pipelined loop needs a few K-steps to pay; 16-bit only
+        if (bn == 256 && desc->dtype == GPP_F32) continue;
         if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding
         if (tile == 2256256 && (desc->C_out < 384 || desc->C_out % 256 != 128 || rows < 256 * 16)) continue;   // dual-shape grid: C_out = 256 k + 128
         float us = 0.0f;
-        int r = time_one(tile, tile == 0 ? split_in : 1, &us);
+        int r = time_one(tile, &us);
         if (r != GPP_OK) { if (tile == 0) { rc = r; break; } continue; }
-        if (us < best) { best = us; best_tile = tile; best_split = tile == 0 ? split_in : 1; }
-        if (tile == 0 || !desc->partial) continue;
-        const int64_t blocks = ((rows + bm - 1) / bm) * ((desc->C_out + bn - 1) / bn);
-        if (blocks >= 512 || nk < 16) continue;                      // split-K only for under-filled deep-K layers
-        for (int split : kSplits) {
-            if (split == 1 || nk / split < (split > 8 ? 4 : 8)) continue;
-            // a split changes the summation order: take it only for a clear (> 3 %) win
-            if (time_one(tile, split, &us) == GPP_OK && us < 0.97f * best) { best = us; best_tile = tile; best_split = split; }
-        }
+        if (us < best) { best = us; best_tile = tile; }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     desc->tile_hint = rc == GPP_OK ? best_tile : tile_in;
-    desc->split_k = rc == GPP_OK ? best_split : split_in;
     if (best_us) *best_us = best;
     return rc;
 }

@@ -3,6 +3,8 @@
 // launches as calling those entry points one by one from the host language.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "gpp.h"
 
 namespace {
@@ -11,12 +13,17 @@ namespace {
 // library-owned stream that forks from the caller's stream where the lane is first used; a lane-0 op
 // marked GPP_OP_JOIN (and the end of the plan) waits for all open lanes.  Independent chains of the graph (the three head
 // towers) overlap their ramp-up / tail phases this way; results do not change.
+// The side streams and their events belong to ONE device: there is a set per device ordinal, created on first use under
+// a lock, and a plan that uses lanes holds that device's lock while it enqueues (two host threads driving the same
+// device would otherwise interleave their fork / join events on the shared side streams).  Plans without lanes take no lock.
 constexpr int kLanes = 2;
+constexpr int kMaxDevices = 64;
 struct Lanes {
+    std::mutex lock;
     hipStream_t stream[kLanes] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, done[kLanes] = {nullptr, nullptr};
     bool ready = false;
-    int init()
+    int init()                                          // call with `lock` held
     {
         if (ready) return GPP_OK;
         int lo = 0, hi = 0;                             // side lanes carry the short latency-bound chains: let their workgroups in first
@@ -33,7 +40,7 @@ struct Lanes {
         return GPP_OK;
     }
 };
-Lanes g_lanes;
+Lanes g_lanes_of_device[kMaxDevices];
 
 }  // namespace
 
@@ -43,6 +50,17 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
     hipStream_t main_st = (hipStream_t)stream;
     int ev = 0;
     bool active[kLanes] = {false, false};
+    bool uses_lanes = false;
+    for (int i = 0; i < n_ops; ++i) uses_lanes = uses_lanes || ((ops[i].kind >> 8) & 0xff) != 0;
+    int dev = 0;
+    if (uses_lanes) {
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (dev < 0 || dev >= kMaxDevices) return GPP_ERR_UNSUPPORTED;
+    }
+    Lanes& g_lanes = g_lanes_of_device[dev];
+    std::unique_lock<std::mutex> guard(g_lanes.lock, std::defer_lock);
+    if (uses_lanes) guard.lock();
     for (int i = 0; i < n_ops; ++i) {
         gpp_plan_op op = ops[i];
         if (!op.desc) return GPP_ERR_BAD_ARG;
@@ -80,7 +98,10 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
         switch (op.kind) {
         case GPP_OP_STEM: {
             const gpp_stem_desc* d = (const gpp_stem_desc*)op.desc;
-            rc = gpp_stem_conv7x7_bn_relu_mfma(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
+            if (d->dtype == GPP_F32)      // reference-precision path: float32 [147][64] weights, fmaf chain on the vector ALUs
+                rc = gpp_stem_conv7x7_bn_relu(d->in, (const float*)d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
+            else
+                rc = gpp_stem_conv7x7_bn_relu_mfma(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
             break;
         }
         case GPP_OP_MAXPOOL: {

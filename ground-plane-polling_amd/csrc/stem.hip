@@ -22,6 +22,8 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) float f32x8_natural;
+typedef f32x8_natural f32x8 __attribute__((aligned(16)));     // 8 floats, accessed as two 16-byte halves (GPP_F32 maps)
 
 constexpr int TW = 64, TH = 4;                 // output tile
 constexpr int PW = TW * 2 + 5, PH = TH * 2 + 5;  // input patch
@@ -290,6 +292,8 @@ extern "C" int gpp_stem_conv7x7_bn_relu(const float* in, const float* weight, co
         stem_kernel<__bf16, bf16x8><<<grid, 256, 0, st>>>(in, weight, bias, (__bf16*)out, H, W, Ho, Wo);
     else if (dtype == GPP_F16)
         stem_kernel<_Float16, f16x8><<<grid, 256, 0, st>>>(in, weight, bias, (_Float16*)out, H, W, Ho, Wo);
+    else if (dtype == GPP_F32)
+        stem_kernel<float, f32x8><<<grid, 256, 0, st>>>(in, weight, bias, (float*)out, H, W, Ho, Wo);
     else
         return GPP_ERR_UNSUPPORTED;
     return result();
@@ -354,6 +358,8 @@ extern "C" int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B
         maxpool_kernel<__bf16, bf16x8><<<blocks, 256, 0, st>>>((const __bf16*)in, (__bf16*)out, B, H, W, C, Ho, Wo, pt, pl);
     else if (dtype == GPP_F16)
         maxpool_kernel<_Float16, f16x8><<<blocks, 256, 0, st>>>((const _Float16*)in, (_Float16*)out, B, H, W, C, Ho, Wo, pt, pl);
+    else if (dtype == GPP_F32)
+        maxpool_kernel<float, f32x8><<<blocks, 256, 0, st>>>((const float*)in, (float*)out, B, H, W, C, Ho, Wo, pt, pl);
     else
         return GPP_ERR_UNSUPPORTED;
     return result();
@@ -372,6 +378,8 @@ extern "C" int gpp_relu_strided(const void* in, int64_t in_bstride, void* out, i
         relu_kernel<__bf16, bf16x8><<<grid, 256, 0, st>>>((const __bf16*)in, in_bstride, (__bf16*)out, out_bstride, n8);
     else if (dtype == GPP_F16)
         relu_kernel<_Float16, f16x8><<<grid, 256, 0, st>>>((const _Float16*)in, in_bstride, (_Float16*)out, out_bstride, n8);
+    else if (dtype == GPP_F32)
+        relu_kernel<float, f32x8><<<grid, 256, 0, st>>>((const float*)in, in_bstride, (float*)out, out_bstride, n8);
     else
         return GPP_ERR_UNSUPPORTED;
     return result();

@@ -35,6 +35,7 @@ c_int64 = ctypes.c_int64
 
 GPP_BF16 = 1
 GPP_F16 = 2
+GPP_F32 = 3
 GPP_MAX_GROUPS = 5
 
 
@@ -104,6 +105,20 @@ def _declare(lib):
     lib.gpp_detect_stages_f32.argtypes = [c_int] + lib.gpp_detect_f32.argtypes
     lib.gpp_conv2d_flops.restype = c_int
     lib.gpp_conv2d_flops.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_double)]
+    lib.gpp_conv2d_split_rule.restype = c_int
+    lib.gpp_conv2d_split_rule.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int)]
+    lib.gpp_conv2d_workspace_bytes.restype = c_int
+    lib.gpp_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_size_t)]
+    lib.gpp_plan_run.restype = c_int
+    lib.gpp_plan_run.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int]
+    lib.gpp_event_create.restype = c_int
+    lib.gpp_event_create.argtypes = [ctypes.POINTER(c_void_p)]
+    lib.gpp_event_destroy.restype = c_int
+    lib.gpp_event_destroy.argtypes = [c_void_p]
+    lib.gpp_event_elapsed_ms.restype = c_int
+    lib.gpp_event_elapsed_ms.argtypes = [c_void_p, c_void_p, ctypes.POINTER(c_float)]
+    lib.gpp_conv2d_autotune.restype = c_int
+    lib.gpp_conv2d_autotune.argtypes = [ctypes.POINTER(ConvDesc), c_int, c_void_p, ctypes.POINTER(c_float)]
 
 
 def build(verbose=False):

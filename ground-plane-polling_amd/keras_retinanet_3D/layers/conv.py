@@ -17,11 +17,20 @@ from ..backend import hip
 
 def torch_dtype(dtype):
     import torch
-    return {'bf16': torch.bfloat16, 'f16': torch.float16}[dtype]
+    return {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtype]
 
 
 def gpp_dtype(dtype):
-    return {'bf16': hip.GPP_BF16, 'f16': hip.GPP_F16}[dtype]
+    return {'bf16': hip.GPP_BF16, 'f16': hip.GPP_F16, 'f32': hip.GPP_F32}[dtype]
+
+
+def elem_size(dtype):
+    return 4 if dtype == 'f32' else 2
+
+
+def k_chunk(dtype):
+    """ channels per K-step = 128 bytes of one pixel (include/gpp.h: CK) """
+    return 128 // elem_size(dtype)
 
 
 class FMap(object):
@@ -48,14 +57,16 @@ class FMap(object):
 
 def pack_weight(kernel_hwio, dtype, device):
     """ Keras HWIO float32 kernel (KH, KW, C_in, C_out) -> device tensor
-    [C_out rounded up to 256][KH*KW*C_in] in the compute type, K ordered (64-channel chunk, kh, kw, channel). """
+    [C_out rounded up to 256][KH*KW*C_in] in the compute type, K ordered (channel chunk, kh, kw, channel in chunk);
+    a chunk is 128 bytes of channels: 64 for the 16-bit types, 32 for float32. """
     import torch
     k = torch.as_tensor(np.ascontiguousarray(kernel_hwio, dtype=np.float32))
     KH, KW, Cin, Cout = k.shape
     rows = ((Cout + 255) // 256) * 256
+    ck = k_chunk(dtype)
     w = torch.zeros((rows, KH * KW * Cin), dtype=torch.float32)
-    # K order (chunk of 64 input channels, kh, kw, 64 channels): see include/gpp.h
-    w[:Cout] = k.permute(3, 0, 1, 2).reshape(Cout, KH * KW, Cin // 64, 64).permute(0, 2, 1, 3).reshape(Cout, KH * KW * Cin)
+    # K order (chunk of CK input channels, kh, kw, CK channels): see include/gpp.h
+    w[:Cout] = k.permute(3, 0, 1, 2).reshape(Cout, KH * KW, Cin // ck, ck).permute(0, 2, 1, 3).reshape(Cout, KH * KW * Cin)
     w = w[weight_row_order(rows)]
     return w.to(torch_dtype(dtype)).to(device).contiguous()
 
@@ -95,7 +106,6 @@ def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=
     """ Build a gpp_conv_desc.  inputs / outputs / residuals are lists of FMap (one per group,
     all groups share weights; every list member must live in the same torch buffer). """
     d = hip.ConvDesc()
-    esz = 2
     d.inp = inputs[0].buf.data_ptr()
     d.weight = weight.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -113,7 +123,7 @@ def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=
     d.relu = int(relu)
     d.n_groups = len(inputs)
     d.tile_hint = int(tile_hint)
-    d.reserved = int(diag)          # diagnostic ablation bits (timing experiments only)
+    d.reserved = int(diag)          # diagnostic ablation bits (-DGPP_STAMPS build only; the production library rejects non-zero)
     if workspace is not None:       # split-K partial tiles (float32); the library decides whether to split
         d.partial = workspace.data_ptr()
         d.partial_bytes = workspace.numel() * workspace.element_size()
@@ -133,12 +143,24 @@ def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=
             G.res_off, G.res_bstride, G.H_res, G.W_res = fr.off, fr.bstride, fr.H, fr.W
         else:
             G.H_res, G.W_res = fo.H, fo.W
-    del esz
     return d
 
 
 def run_conv(desc):
     hip.check(hip.lib().gpp_conv2d_igemm(ctypes.byref(desc), hip.stream_ptr()), 'gpp_conv2d_igemm')
+
+
+def split_rule(desc):
+    """ split-K factor the library will use for this layer (a function of the layer alone, include/gpp.h) """
+    k = ctypes.c_int(0)
+    hip.check(hip.lib().gpp_conv2d_split_rule(ctypes.byref(desc), ctypes.byref(k)), 'gpp_conv2d_split_rule')
+    return k.value
+
+
+def workspace_bytes(desc):
+    n = hip.c_size_t(0)
+    hip.check(hip.lib().gpp_conv2d_workspace_bytes(ctypes.byref(desc), ctypes.byref(n)), 'gpp_conv2d_workspace_bytes')
+    return int(n.value)
 
 
 def conv_flops(desc):

@@ -16,12 +16,15 @@ that one `gpp_plan_run` call enqueues on the current HIP stream.  All arithmetic
 hand-written kernels of ../csrc; PyTorch only owns the device buffers.
 
 HBM layout
-  * activations NHWC, 16-bit (bf16 default), one dense buffer per live tensor
+  * activations NHWC, 16-bit (bf16 default, f16) or float32 (dtype='f32': the reference's own arithmetic type --
+    float32 operands on v_mfma_f32_16x16x4_f32, float32 stem, no fused bottleneck tails), one dense buffer per live tensor
   * the five pyramid levels of every FPN / head tensor are stored back to back per image,
     (B, 11438, C) for a 402x1333 input, so that one grouped launch covers all levels and the head
     outputs come out directly in the reference's concatenated (B, A, k) order
   * head outputs (classification logits, fused 144-channel regression, dimensions) float32
-  * weights [C_out][KH*KW*C_in] 16-bit with the frozen BatchNormalization folded in, biases float32
+  * weights [C_out][KH*KW*C_in] in the storage type with the frozen BatchNormalization folded in, biases float32
+Every bit of a result is a function of (image, weights, dtype) alone: block tiles are tuned by timing but never change
+a result, and split-K follows a rule of the layer alone (gpp_conv2d_split_rule) -- not of the batch size or the rank.
 """
 
 import ctypes
@@ -126,7 +129,10 @@ class RetinaNet3D(object):
         self.backbone_name = backbone_name.split('_')[0]
         if self.backbone_name not in W.BLOCKS:
             raise ValueError('Backbone (\'{}\') not in allowed backbones ({}).'.format(backbone_name, sorted(W.BLOCKS)))
+        if dtype not in ('bf16', 'f16', 'f32'):
+            raise ValueError("dtype must be 'bf16', 'f16' or 'f32', got {!r}".format(dtype))
         self.dtype = dtype
+        self.esz = C.elem_size(dtype)
         self.tdtype = C.torch_dtype(dtype)
         self.device = hip.require_device()
         hip.lib()
@@ -152,7 +158,10 @@ class RetinaNet3D(object):
             if k.shape != (kh, kw, cin, cout):
                 raise ValueError('weight {} has shape {}, expected {}'.format(conv, k.shape, (kh, kw, cin, cout)))
             if conv == 'conv1':
-                self.stem_w = hip.pack_stem_weights(k.reshape(147, 64), dev)
+                if self.dtype == 'f32':      # float32 stem on the vector ALUs: the folded kernel as it is, [147][64]
+                    self.stem_w = torch.as_tensor(np.ascontiguousarray(k.reshape(147, 64), dtype=np.float32)).to(dev).contiguous()
+                else:
+                    self.stem_w = hip.pack_stem_weights(k.reshape(147, 64), dev)
                 self.stem_b = torch.as_tensor(b).to(dev).contiguous()
             else:
                 put(conv, k, b)
@@ -180,8 +189,12 @@ class RetinaNet3D(object):
         kh, kw, cin, cout = shape
         if pad is None:
             pad = (0, 0)
-        return C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
-                           residuals=residuals, dtype=self.dtype, out_f32=out_f32, workspace=plan.workspaces[lane])
+        d = C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
+                        residuals=residuals, dtype=self.dtype, out_f32=out_f32)
+        # split-K partial tiles: the workspace of this op's stream lane is allocated once every op is known (_build)
+        plan.conv_descs.append((d, lane))
+        plan.ws_need[lane] = max(plan.ws_need.get(lane, 0), C.workspace_bytes(d))
+        return d
 
     def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0, lane=0,
               join=False):
@@ -216,11 +229,10 @@ class RetinaNet3D(object):
         torch, dev, dt = self.torch, self.device, self.tdtype
         plan = Plan()
         plan.shape = (B, H, Wd, n_planes, planes_batched)
-        # split-K partial tiles of the under-filled deep-K layers (res5, P5..P7); reused by every launch
-        # (one per stream lane: concurrent launches must not share partial tiles)
+        # split-K partial tiles of the deep-K layers with a tiny per-image grid (res5 branch2b, P5..P7); one workspace per
+        # stream lane (concurrent launches must not share partial tiles), sized from the descriptors at the end of _build
         head_lanes = os.environ.get('GPP_HEAD_LANES', '0') != '0'
-        plan.workspaces = [torch.empty((64 << 20,), dtype=torch.uint8, device=dev) for _ in range(3 if head_lanes else 2)]
-        plan.workspace = plan.workspaces[0]
+        plan.conv_descs, plan.ws_need = [], {}
 
         def fmap(h, w, c, dtype=None):
             f = C.FMap.empty(B, h, w, c, dtype or dt, dev)
@@ -253,6 +265,8 @@ class RetinaNet3D(object):
         # whole step: none 1553, res3 only 1562, res2 + res3 1571 images/s (in isolation the fused res2 launch is no
         # faster than its two layers -- 122 us vs 36 + 80 -- but the step is: 69 MB less through HBM per block)
         fuse_tail = [int(v) for v in os.environ.get('GPP_FUSE_TAIL', '64,128').split(',') if v.strip() and int(v) > 0]
+        if self.dtype == 'f32':
+            fuse_tail = []              # the fused tail keeps a 16-bit intermediate tile in LDS: 16-bit storage types only
 
         # GPP_FUSE_NEXT=1: additionally the first 1x1 layer of the FOLLOWING identity block in the same launch
         # (gpp_bottleneck_tail_next: y feeds the next product from registers, bit-identical).  Off by default -- measured
@@ -331,7 +345,7 @@ class RetinaNet3D(object):
         self._conv(plan, 'P5', [T5], [P[2]], 3, pad=(1, 1), lane=l_p5)
         self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]), lane=l_p6)
         R6 = fmap(shapes[3][0], shapes[3][1], 512)
-        plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * 2, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
+        plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * self.esz, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
                                    pix[3] * 512, C.gpp_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
         plan.relu_io = (P[3], R6)
         self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
@@ -447,6 +461,10 @@ class RetinaNet3D(object):
                       plan.best_index.data_ptr(), plan.poll_ws.data_ptr(), plan.poll_ws.numel(), B, D, n_planes,
                       int(planes_batched), POLL_THRESHOLD, 0)
         plan.add(OP_POLL, pd, 'fit_road_planes', tag=2, flops=162.0 * B * D * n_planes)      # tag 2: bench.py times it live too
+        plan.workspaces = {lane: torch.empty((max(need_, 16),), dtype=torch.uint8, device=dev) for lane, need_ in plan.ws_need.items()}
+        for d, lane in plan.conv_descs:
+            d.partial = plan.workspaces[lane].data_ptr()
+            d.partial_bytes = plan.workspaces[lane].numel()
         plan.finalize()
         plan.tagged = [name for _, tag, _, name, _ in plan.ops if tag]
         if os.environ.get('GPP_AUTOTUNE', '1') != '0':
@@ -464,29 +482,36 @@ class RetinaNet3D(object):
                 for key, val in json.load(f).items():
                     bb, dt, name, b, h, w = key.split('|')
                     if bb == self.backbone_name and dt == self.dtype:
-                        self._tuned[(name, int(b), int(h), int(w))] = tuple(val)
+                        # [tile, us]; files written by round 1 hold [tile, split_k, us] -- the split is ignored (never tuned now)
+                        self._tuned[(name, int(b), int(h), int(w))] = (int(val[0]), float(val[-1]))
 
     def _save_tune_cache(self):
+        """ Rank 0 only, through a temporary file + os.replace: readers never see a torn file, ranks never race. """
         path = self._tune_cache_path()
-        if not path:
+        if not path or int(os.environ.get('RANK', '0')) != 0:
             return
         data = {}
         if os.path.exists(path):
-            with open(path) as f:
-                data = json.load(f)
+            try:
+                with open(path) as f:
+                    data = json.load(f)
+            except ValueError:
+                data = {}
         for (name, b, h, w), val in self._tuned.items():
             data['|'.join([self.backbone_name, self.dtype, name, str(b), str(h), str(w)])] = list(val)
-        with open(path, 'w') as f:
+        tmp = '{}.tmp.{}'.format(path, os.getpid())
+        with open(tmp, 'w') as f:
             json.dump(data, f, indent=0, sort_keys=True)
+        os.replace(tmp, path)
 
     def _autotune(self, plan):
-        """ Choose the block tile and split-K of every conv layer of this plan by timing the candidates on
-        the device (gpp_conv2d_autotune), layer by layer on realistic activations (a noise frame pushed
-        through the layers before).  Whether a layer's tile grid fills the 256 CUs in 1.07 or 0.95 rounds
-        decides its time by up to 1.5x and is cheap to measure.  Tile choice never changes results; split-K
-        changes the float32 summation order (last bits), so decisions are remembered per (layer, batch,
-        image size) -- every plan of a model makes the same ones -- and can be persisted with
-        GPP_TUNE_CACHE=<file.json>.  GPP_AUTOTUNE=0 keeps the library heuristic. """
+        """ Choose the block tile of every conv layer of this plan by timing the candidates on the device
+        (gpp_conv2d_autotune), layer by layer on realistic activations (a noise frame pushed through the layers
+        before).  Whether a layer's tile grid fills the 256 CUs in 1.07 or 0.95 rounds decides its time by up to 1.5x
+        and is cheap to measure.  The tile NEVER changes a result (same K order per output element,
+        test_every_tile_gives_identical_results), so ranks and plans may choose differently without any effect on the
+        outputs; split-K, which would, is not tuned (gpp_conv2d_split_rule).  Choices are remembered per (layer, batch,
+        image size) and can be persisted with GPP_TUNE_CACHE=<file.json>.  GPP_AUTOTUNE=0 keeps the library heuristic. """
         torch = self.torch
         B, H, Wd = plan.shape[:3]
         plan.images.uniform_(-120.0, 130.0)
@@ -513,7 +538,7 @@ class RetinaNet3D(object):
                         e1.synchronize()
                         times[rows] = e0.elapsed_time(e1) * 1000.0 / 16
                     rows = min(times, key=times.get)
-                    self._tuned[key] = (rows, 1, round(times[rows], 2))
+                    self._tuned[key] = (rows, round(times[rows], 2))
                     fresh = True
                 desc.tile_rows = self._tuned[key][0]
                 plan.tuning[name] = self._tuned[key]
@@ -522,12 +547,12 @@ class RetinaNet3D(object):
                 continue
             key = (name, B, H, Wd)
             if key not in self._tuned:
-                iters = 4 if flops > 5e10 else 16
+                iters = (2 if self.dtype == 'f32' else 4) if flops > 5e10 else (4 if self.dtype == 'f32' else 16)
                 hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(desc), iters, hip.stream_ptr(), ctypes.byref(best)),
                           'gpp_conv2d_autotune')
-                self._tuned[key] = (int(desc.tile_hint), int(desc.split_k), round(float(best.value), 2))
+                self._tuned[key] = (int(desc.tile_hint), round(float(best.value), 2))
                 fresh = True
-            desc.tile_hint, desc.split_k = self._tuned[key][0], self._tuned[key][1]
+            desc.tile_hint = self._tuned[key][0]
             plan.tuning[name] = self._tuned[key]
         torch.cuda.synchronize()
         if fresh:

@@ -1,0 +1,95 @@
+"""
+End-to-end parity ledger between two runs of the predict_on_batch path on the same inputs -- a run at the reference's
+arithmetic precision (float32) and a run at a narrower storage type (bf16 / f16), or the float32 HIP path against the
+CPU oracle.
+
+What the reference returns from bin/run_network.py:110 is decided AFTER the conv stack by
+layers/filter_detections.py:54-64,155-177 (threshold, NMS, top-k) and layers/fit_road_planes.py:112-137 (masked
+arg-min over the plane database), so agreement is measured there, in the terms BASELINE.json's north_star uses:
+
+    detection-set agreement     which anchors survive threshold + NMS + top-k (identified by anchor id)
+    orientation / plane index   on the detections both runs report: same orientation class, same selected plane
+    corner deviation            max distance between the 8 cuboid corners (run_network.py:137-310) of such a detection,
+                                and between the four 3-D keypoints the polling layer returns, in metres
+
+Nothing here is reference code; it is the measurement both bench.py and tests/ report.
+"""
+
+import numpy as np
+
+from . import gpp_utils
+
+
+def _dev(a, b):
+    """ |a - b| element-wise in float64; a non-finite value (a degenerate pose of a random-weight detection) counts as
+    equal when both runs produce it at the same place, as an infinite deviation otherwise """
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    with np.errstate(invalid='ignore'):
+        d = np.abs(a - b)
+    return np.where(fa & fb, d, np.where(~fa & ~fb, 0.0, np.inf))
+
+
+def _per_image(outs, anchor_index, plane_index, b):
+    det = gpp_utils.select_detections(outs, 1.0, image_index=b)
+    scores = np.asarray(outs[2][b])
+    idx = np.where(scores > 0.05)[0]
+    order = idx[np.argsort(-scores[idx], kind='stable')[:100]]
+    det['anchor'] = np.asarray(anchor_index[b])[order]
+    det['plane'] = np.asarray(plane_index[b])[order]
+    return det
+
+
+def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane):
+    """ ref_* : the 8 output arrays + (B, 100) anchor ids + (B, 100) selected plane indices of the reference-precision
+    run; outs / anchor / plane: the same of the run under test.  Returns a dict of plain numbers. """
+    B = int(np.asarray(ref_outs[0]).shape[0])
+    n_ref = n_got = n_common = 0
+    same_orient = same_plane = 0
+    max_kp = max_corner = max_box = max_score = 0.0
+    max_kp_same_plane = max_corner_same_plane = 0.0
+    identical_images = 0
+    for b in range(B):
+        A = _per_image(ref_outs, ref_anchor, ref_plane, b)
+        G = _per_image(outs, anchor, plane, b)
+        pos_a = {int(a): i for i, a in enumerate(A['anchor'])}
+        pos_g = {int(a): i for i, a in enumerate(G['anchor'])}
+        common = sorted(set(pos_a) & set(pos_g))
+        n_ref += len(pos_a)
+        n_got += len(pos_g)
+        n_common += len(common)
+        identical_images += int(list(A['anchor']) == list(G['anchor']))
+        if not common:
+            continue
+        ia = np.array([pos_a[a] for a in common])
+        ig = np.array([pos_g[a] for a in common])
+        so = A['orientations'][ia] == G['orientations'][ig]
+        sp = so & (A['plane'][ia] == G['plane'][ig])
+        same_orient += int(so.sum())
+        same_plane += int(sp.sum())
+        max_box = max(max_box, float(np.abs(A['boxes'][ia] - G['boxes'][ig]).max()))
+        max_score = max(max_score, float(np.abs(A['scores'][ia] - G['scores'][ig]).max()))
+        kp = _dev(A['keypoints'][ia], G['keypoints'][ig]).reshape(len(common), -1).max(axis=1)
+        # the 8 cuboid corners are only comparable when both runs chose the same orientation (the pose branches differ)
+        with np.errstate(all='ignore'):
+            ca = gpp_utils.cuboid_corners(gpp_utils.recover_pose({k: v[ia] for k, v in A.items()}))
+            cg = gpp_utils.cuboid_corners(gpp_utils.recover_pose({k: v[ig] for k, v in G.items()}))
+        cd = _dev(ca, cg).reshape(len(common), -1).max(axis=1)
+        if so.any():
+            max_kp = max(max_kp, float(kp[so].max()))
+            max_corner = max(max_corner, float(cd[so].max()))
+        if sp.any():
+            max_kp_same_plane = max(max_kp_same_plane, float(kp[sp].max()))
+            max_corner_same_plane = max(max_corner_same_plane, float(cd[sp].max()))
+    union = n_ref + n_got - n_common
+    return {
+        'images': B, 'detections_ref': n_ref, 'detections': n_got, 'common': n_common,
+        'detection_set_agreement': round(n_common / union, 6) if union else 1.0,          # Jaccard index over anchor ids
+        'detection_recall_of_ref': round(n_common / n_ref, 6) if n_ref else 1.0,
+        'images_with_identical_detection_lists': identical_images,
+        'orientation_agreement': round(same_orient / n_common, 6) if n_common else 1.0,
+        'plane_index_agreement': round(same_plane / n_common, 6) if n_common else 1.0,
+        'max_score_diff': max_score, 'max_box_diff_px': max_box,
+        'max_keypoint_dev_m': max_kp, 'max_corner_dev_m': max_corner,
+        'max_keypoint_dev_m_same_plane': max_kp_same_plane, 'max_corner_dev_m_same_plane': max_corner_same_plane,
+    }

@@ -17,7 +17,8 @@
  *     workspaces whose sizes are reported by the *_workspace_bytes functions
  *   - all pointers are DEVICE pointers unless named host_*; kernels are enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream) and run asynchronously
- *   - no global state; safe to call from several host threads on distinct streams
+ *   - no global state except per-device launch configuration and the side streams of gpp_plan_run lanes (both
+ *     created on first use under a lock, one set per device); safe to call from several host threads on distinct streams
  *   - tensors are dense, row-major, NHWC for images / feature maps
  */
 #ifndef GPP_H_
@@ -71,6 +72,9 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
  * ---------------------------------------------------------------------------------------- */
 #define GPP_BF16 1   /* bfloat16 storage, float32 MFMA accumulation (default compute type) */
 #define GPP_F16 2    /* IEEE half storage, float32 MFMA accumulation */
+#define GPP_F32 3    /* float32 storage AND float32 operands (v_mfma_f32_16x16x4_f32: every product rounded once, float32
+                        accumulation): the arithmetic type of the reference, keras.backend.floatx() = float32
+                        (utils/image.py:47, placeholders models/retinanet.py:395-396).  1/16 of the 16-bit MFMA rate. */
 
 /* ------------------------------------------------------------------------------------------
  * 2-D convolution, NHWC, implicit GEMM on MFMA (no im2col buffer), fused epilogue
@@ -83,10 +87,11 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
  * One launch covers up to GPP_MAX_GROUPS independent feature maps that share the weights
  * (the five pyramid levels of a head layer, retinanet.py:257-281), each described by a
  * gpp_conv_group.  GEMM view per group: M = batch*H_out*W_out output pixels, N = C_out,
- * K = KH*KW*C_in, K ordered (c_in / 64, kh, kw, c_in % 64): the taps of one 64-channel chunk are
- * adjacent so that their overlapping input rows are re-read from the XCD-local L2.
+ * K = KH*KW*C_in, K ordered (c_in / CK, kh, kw, c_in % CK) with CK = 128 bytes of channels (64 for the 16-bit types,
+ * 32 for GPP_F32): the taps of one channel chunk are adjacent so that their overlapping input rows are re-read
+ * from the XCD-local L2.
  *
- * Layouts (element = 2 bytes, GPP_BF16 or GPP_F16)
+ * Layouts (element = 2 bytes for GPP_BF16 / GPP_F16, 4 bytes for GPP_F32)
  *   in        pixel (b, y, x) of a group at  in + in_off + b*in_bstride + (y*W_in + x)*in_pitch,
  *             C_in contiguous channels there (in_pitch >= C_in lets a channel slice be read)
  *   weight    [C_out rounded up to a multiple of 256][KH*KW*C_in], K contiguous; rows >= C_out
@@ -100,8 +105,8 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
  *             src = min(floor(dst * in/out), in-1)  (tf.image.resize_images, align_corners=False)
  *   out       element type = dtype, or float32 when out_f32 != 0
  *   zero_page unused since v0.2 (padding comes from range-checked buffer loads); may be NULL
- * Requirements: C_in % 64 == 0; C_out % 4 == 0; in_pitch, out_pitch, res_pitch multiples of 8
- * (4 for float32 out); all base pointers 16-byte aligned; stride in {1, 2}.
+ * Requirements: C_in % CK == 0; C_out % 4 == 0; in_pitch, out_pitch, res_pitch multiples of 16 bytes
+ * (8 elements; 4 for float32); all base pointers 16-byte aligned; stride in {1, 2}.
  * Padding is explicit (pad_top, pad_left); bottom/right padding is implied by H_out/W_out
  * (this covers Keras 'same' at stride 1, TF's asymmetric 'same' at stride 2, and
  * ZeroPadding2D + 'valid').  Every input map and the weight tensor must be smaller than 2 GiB.
@@ -125,7 +130,7 @@ typedef struct gpp_conv_desc {
     const void* residual;
     void* out;
     const void* zero_page;
-    int32_t dtype;                  /* GPP_BF16 | GPP_F16 */
+    int32_t dtype;                  /* GPP_BF16 | GPP_F16 | GPP_F32 */
     int32_t out_f32;
     int32_t batch, C_in, C_out, KH, KW, stride, pad_top, pad_left;
     int32_t in_pitch, out_pitch, res_pitch;   /* elements per pixel */
@@ -137,29 +142,38 @@ typedef struct gpp_conv_desc {
                                        192160), 2256256 = 256256 plus 512 x 128 tiles for the last 128 columns in one grid
                                        (C_out = 256 k + 128 only); legacy codes 64 / 128 / 256 / 512; anything else: GPP_ERR_BAD_ARG.
                                        See gpp_conv2d_autotune */
-    int32_t reserved;               /* 0.  Timing experiments only (tools/bench_conv.py): bit 0 skip the tile loads, bit 1 skip
-                                       the LDS reads + MFMA, bit 2 / 3 flip the pipelined form of the 128128 / 256256 tile;
-                                       bits 4, 5 enable the in-kernel stamps of a -DGPP_STAMPS build (written through zero_page) */
+    int32_t reserved;               /* must be 0 (anything else: GPP_ERR_BAD_ARG).  Only the diagnostic -DGPP_STAMPS build of the
+                                       library (make stamps; tools/bench_conv.py) reads it: bit 0 skip the tile loads, bit 1 skip
+                                       the LDS reads + MFMA, bit 2 / 3 flip the pipelined form of the 128128 / 256256 tile,
+                                       bits 4, 5 enable in-kernel time stamps (written through zero_page) */
     int32_t in_bytes, weight_bytes; /* filled in by the library: extents for the range-checked buffer loads */
     void* partial;                  /* optional split-K workspace (float32 partial tiles), 16-byte aligned; NULL = never split */
-    int64_t partial_bytes;
-    int32_t split_k;                /* 0 = library decides, 1 = never, k > 1 = force k splits (tests) */
+    int64_t partial_bytes;          /* >= gpp_conv2d_workspace_bytes(), else GPP_ERR_WORKSPACE when the layer is split */
+    int32_t split_k;                /* 0 = gpp_conv2d_split_rule (a function of the layer alone), 1 = never, k > 1 = exactly k */
     int32_t partial_rows;           /* filled in by the library */
     gpp_conv_group groups[GPP_MAX_GROUPS];
 } gpp_conv_desc;
 
 int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream);
 
-/* Time the tile / split-K candidates of this layer on the device (iters launches each; the layer only rewrites its own
-   output) and store the fastest in desc->tile_hint / desc->split_k.  best_us (optional): its time per launch.
-   Synchronises the stream.  Results do not depend on the tile choice; they depend on split_k only in the last bits. */
+/* Split-K factor the library uses for this layer when desc->split_k == 0 and a workspace is given.  It is a function of
+   the layer alone (kernel size, channels, output pixels PER IMAGE) -- never of the batch size, the block tile or a timing --
+   so the float32 summation order of every output element, hence every bit of a result, is the same whether an image is
+   computed alone, inside a larger batch or on another rank.  gpp_conv2d_workspace_bytes: size of `partial` that any
+   block tile of this layer may need (0 when the layer is not split). */
+int gpp_conv2d_split_rule(const gpp_conv_desc* host_desc, int* split_k);
+int gpp_conv2d_workspace_bytes(const gpp_conv_desc* host_desc, size_t* bytes);
+
+/* Time the block-tile candidates of this layer on the device (iters launches each; the layer only rewrites its own
+   output) and store the fastest in desc->tile_hint.  best_us (optional): its time per launch.  Synchronises the stream.
+   Results do not depend on the tile (same K order per output element); split_k is used as given, never tuned. */
 int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* best_us);
 
 /* Fused tail of a ResNet bottleneck (keras_resnet bottleneck_2d, used at /root/reference/keras_retinanet_3D/models/
    resnet.py:88-93): the 3x3 conv "branch2b" (C -> C, C = 64 or 128, stride 1, pad 1, + bias + ReLU) and the 1x1 conv
    "branch2c" (C -> multiple of 128, + bias + residual + ReLU) in ONE launch; the intermediate map stays in LDS.
    conv3x3->out is not written.  Results are bit-identical to gpp_conv2d_igemm(conv3x3) + gpp_conv2d_igemm(conv1x1).
-   tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup.  Other shapes: GPP_ERR_UNSUPPORTED. */
+   tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup.  Other shapes, and GPP_F32: GPP_ERR_UNSUPPORTED. */
 int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream);
 
 /* The same launch extended by the FIRST layer of the following identity bottleneck ("branch2a": 1x1, 4C -> C, + bias +
@@ -178,7 +192,8 @@ int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
  * no bias) + bn_conv1 (frozen, eps 1e-5) + ReLU (instantiated at models/resnet.py:88-93):
  *   in (B, H, W, 3) float32 BGR mean-subtracted (utils/image.py:36-62), weight [7*7*3][64]
  *   float32 = Keras HWIO kernel with the BN scale folded in, bias [64] = folded BN shift,
- *   out (B, Ho, Wo, 64) of `dtype`, Ho = (H + 6 - 7)/2 + 1.
+ *   out (B, Ho, Wo, 64) of `dtype`, Ho = (H + 6 - 7)/2 + 1.  Float32 fmaf chain on the vector ALUs: the stem of the
+ *   GPP_F32 (reference-precision) path; the 16-bit paths use the MFMA form below.
  * gpp_maxpool3x3s2_same replaces MaxPooling2D(3x3, stride 2, padding 'same') 'pool1'.
  * gpp_relu replaces Activation('relu') 'C6_relu' (models/retinanet.py:202).
  * ---------------------------------------------------------------------------------------- */
@@ -303,7 +318,7 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 #define GPP_OP_SYNC 0x20000
 
 typedef struct gpp_stem_desc { const float* in; const void* weight; const float* bias; void* out;
-                               int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem) */
+                               int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem); GPP_F32: float32 [147][64] */
 typedef struct gpp_pool_desc { const void* in; void* out; int32_t dtype, B, H, W, C, reserved; } gpp_pool_desc;
 typedef struct gpp_relu_desc { const void* in; void* out; int64_t in_bstride, out_bstride, count;
                                int32_t dtype, B; } gpp_relu_desc;

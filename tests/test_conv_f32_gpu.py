@@ -1,0 +1,228 @@
+"""
+GPU numerics of the reference-precision (GPP_F32) convolution path: float32 activations and weights on
+v_mfma_f32_16x16x4_f32 -- every product rounded once, float32 accumulation, i.e. the arithmetic type of the reference
+(keras.backend.floatx() = float32, /root/reference/keras_retinanet_3D/utils/image.py:47).
+
+Checked against a float64 torch reference of the same op on UNROUNDED random float32 operands.  The only difference
+is the float32 summation (order and rounding of K = KH*KW*C_in <= 9216 terms): |err| <= 2e-6 * sum_k |a_k b_k| would be
+the textbook bound; the tests use the simpler |err| <= 1e-5 * |ref| + 2e-6 * rms(ref) * sqrt(K) stated next to each assert.
+Also: stem / max-pool / ReLU in float32, split-K, tile invariance, grouped pyramid launches, channel slices.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from keras_retinanet_3D.backend import hip
+from keras_retinanet_3D.layers import conv as C
+from test_conv_gpu import CASES, tf_nearest
+
+pytestmark = pytest.mark.gpu
+
+F32_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128, 128160, 192160]
+
+
+def reference64(x, k, bias, stride, pad_t, pad_l, oh, ow, relu, res):
+    """ float64 reference: x (B,H,W,Cin), k HWIO -> (B,oh,ow,Cout) """
+    B, H, W, _ = x.shape
+    KH, KW = k.shape[:2]
+    pad_b = max((oh - 1) * stride + KH - H - pad_t, 0)
+    pad_r = max((ow - 1) * stride + KW - W - pad_l, 0)
+    xp = F.pad(x.double().permute(0, 3, 1, 2), (pad_l, pad_r, pad_t, pad_b))
+    y = F.conv2d(xp, k.double().permute(3, 2, 0, 1), bias.double(), stride=stride)[:, :, :oh, :ow].permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + (tf_nearest(res, oh, ow) if tuple(res.shape[1:3]) != (oh, ow) else res).double()
+    return torch.relu(y) if relu else y
+
+
+def _layer(case, seed_shift=0):
+    name, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, _ = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + seed_shift)
+    dev = torch.device('cuda')
+    x = torch.randn((B, H, W, Cin), generator=g)
+    k = torch.randn((K, K, Cin, Cout), generator=g) * (2.0 / (K * K * Cin)) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    if pad is None:
+        oh, pt = C.same_pad(H, K, stride)
+        ow, pl = C.same_pad(W, K, stride)
+    else:
+        pt, pl = pad
+        oh, ow = out_hw if out_hw else (H, W)
+    res = None
+    if resmode == 'same':
+        res = torch.randn((B, oh, ow, Cout), generator=g)
+    elif resmode is not None:
+        res = torch.randn((B, resmode[0], resmode[1], Cout), generator=g)
+    ref = reference64(x, k, bias, stride, pt, pl, oh, ow, relu, res)
+    xin = C.FMap(x.to(dev).contiguous(), B, H, W, Cin)
+    out = C.FMap.empty(B, oh, ow, Cout, torch.float32, dev)
+    w = C.pack_weight(k.numpy(), 'f32', dev)
+    rmap = None if res is None else [C.FMap(res.to(dev).contiguous(), B, res.shape[1], res.shape[2], Cout)]
+    ws = torch.empty((32 << 20,), dtype=torch.uint8, device=dev)
+    keep = (xin, w, rmap, ws, bias.to(dev))
+
+    def make(tile, split_k=1, workspace=False):
+        return C.conv_desc([xin], [out], w, keep[4], K, K, Cin, Cout, stride=stride, pad=(pt, pl), relu=relu, residuals=rmap,
+                           dtype='f32', tile_hint=tile, workspace=ws if workspace else None, split_k=split_k)
+    return make, out, ref, K * K * Cin, keep
+
+
+def _check(out, ref, kdepth):
+    got = out.buf.double().cpu()
+    assert torch.isfinite(got).all()
+    rms = float(ref.pow(2).mean().sqrt())
+    err = (got - ref).abs()
+    tol = 1e-5 * ref.abs() + 2e-6 * rms * kdepth ** 0.5          # float32 summation of kdepth terms
+    assert bool((err <= tol).all()), 'max err {} (rms {})'.format(err.max().item(), rms)
+
+
+@pytest.mark.parametrize('tile', [0, 64064, 128128, 192128, 128160])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_f32_matches_float64_reference(case, tile):
+    make, out, ref, kdepth, _ = _layer(case)
+    out.buf.fill_(float('nan'))
+    d = make(tile)
+    bn = tile % 1000 if tile else 64
+    if -(-d.C_out // bn) * bn > d.weight_rows:
+        pytest.skip('tile grid would read past the packed weight rows')
+    C.run_conv(d)
+    _check(out, ref, kdepth)
+    assert abs(C.conv_flops(d) - 2.0 * ref.numel() * kdepth) < 1.0
+
+
+@pytest.mark.parametrize('case', ['3x3_wide', '1x1_res_up_nonint', 'head_out144_f32', '3x3_s2_tfsame', 'deepK'])
+def test_every_f32_tile_gives_identical_results(case):
+    """ the block tile never changes the K order of an output element: all float32 tiles agree bit for bit """
+    make, out, ref, kdepth, _ = _layer([c for c in CASES if c[0] == case][0])
+    C.run_conv(make(128128))
+    base = out.buf.clone()
+    _check(out, ref, kdepth)
+    for tile in F32_TILES:
+        out.buf.fill_(float('nan'))
+        d = make(tile)
+        bn = tile % 1000
+        if -(-d.C_out // bn) * bn > d.weight_rows:
+            assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -1
+            continue
+        C.run_conv(d)
+        assert torch.equal(out.buf, base), tile
+
+
+def test_pipelined_and_wide_tiles_are_16_bit_only():
+    make, _, _, _, _ = _layer(CASES[3])
+    for tile in (256256, 1128128, 1192256, 2256256):
+        assert hip.lib().gpp_conv2d_igemm(ctypes.byref(make(tile)), hip.stream_ptr()) == -4      # GPP_ERR_UNSUPPORTED
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(make(12345)), hip.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize('split', [2, 3, 8])
+@pytest.mark.parametrize('case', ['deepK', '3x3_wide'])
+def test_f32_split_k(case, split):
+    make, out, ref, kdepth, _ = _layer([c for c in CASES if c[0] == case][0])
+    out.buf.fill_(float('nan'))
+    d = make(128128, split_k=split, workspace=True)
+    C.run_conv(d)
+    _check(out, ref, kdepth)
+    first = out.buf.clone()
+    out.buf.fill_(float('nan'))
+    C.run_conv(make(64128, split_k=split, workspace=True))           # another tile, same split: same summation order
+    assert torch.equal(out.buf, first)
+
+
+def test_split_rule_depends_on_the_layer_only():
+    """ gpp_conv2d_split_rule: same answer for every batch size and tile; res5-like and P6-like layers are split """
+    dev = torch.device('cuda')
+    ws = torch.empty((64 << 20,), dtype=torch.uint8, device=dev)
+    for dtype in ('bf16', 'f32'):
+        tdt = C.torch_dtype(dtype)
+        seen = {}
+        for B in (1, 2, 8):
+            for name, (H, W, Cin, Cout, K, stride) in {'res5_2b': (13, 42, 512, 512, 3, 1), 'P6': (13, 42, 2048, 512, 3, 2),
+                                                       'res4_2b': (26, 84, 256, 256, 3, 1), 'C5_reduced': (13, 42, 2048, 512, 1, 1),
+                                                       'P3': (51, 167, 512, 512, 3, 1)}.items():
+                oh, pt = C.same_pad(H, K, stride)
+                ow, pl = C.same_pad(W, K, stride)
+                x = C.FMap.empty(B, H, W, Cin, tdt, dev)
+                o = C.FMap.empty(B, oh, ow, Cout, tdt, dev)
+                w = torch.zeros((512, K * K * Cin), dtype=tdt, device=dev)
+                for tile in (0, 64128, 128128):
+                    d = C.conv_desc([x], [o], w, None, K, K, Cin, Cout, stride=stride, pad=(pt, pl), dtype=dtype, tile_hint=tile, workspace=ws)
+                    s = C.split_rule(d)
+                    assert seen.setdefault(name, s) == s, (name, B, tile)
+                    assert C.workspace_bytes(d) >= (s > 1) * s * B * oh * ow * Cout * 4
+        assert seen['res5_2b'] == 3 and seen['P6'] == 8 and seen['res4_2b'] == 1 and seen['C5_reduced'] == 1 and seen['P3'] == 1, seen
+
+
+def test_f32_grouped_pyramid_and_channel_slices():
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cwide, Cout = 2, 64, 160, 128
+    shapes = [(13, 21), (7, 11), (4, 6), (2, 3), (1, 2)]
+    total = sum(h * w for h, w in shapes)
+    xin = torch.randn((B, total, Cwide), generator=g)
+    k = torch.randn((3, 3, Cin, Cout), generator=g) * 0.05
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    xd = xin.to(dev).contiguous()
+    od = torch.full((B, total, Cout), float('nan'), dtype=torch.float32, device=dev)
+    ins, outs, off = [], [], 0
+    for h, w in shapes:
+        ins.append(C.FMap(xd, B, h, w, Cin, off=off * Cwide + 32, bstride=total * Cwide, pitch=Cwide))
+        outs.append(C.FMap(od, B, h, w, Cout, off=off * Cout, bstride=total * Cout))
+        off += h * w
+    d = C.conv_desc(ins, outs, C.pack_weight(k.numpy(), 'f32', dev), bias.to(dev), 3, 3, Cin, Cout, pad=(1, 1), relu=True, dtype='f32')
+    C.run_conv(d)
+    got = od.double().cpu()
+    off = 0
+    for h, w in shapes:
+        x = xin[:, off:off + h * w, 32:96].reshape(B, h, w, Cin)
+        ref = reference64(x, k, bias, 1, 1, 1, h, w, True, None).reshape(B, h * w, Cout)
+        err = (got[:, off:off + h * w] - ref).abs()
+        assert bool((err <= 1e-5 * ref.abs() + 1e-5).all()), err.max().item()
+        off += h * w
+
+
+def test_f32_rejects_bad_descriptors():
+    dev = torch.device('cuda')
+    x = C.FMap.empty(1, 4, 4, 48, torch.float32, dev)        # C_in not a multiple of 32
+    o = C.FMap.empty(1, 4, 4, 64, torch.float32, dev)
+    w = torch.zeros((256, 48), dtype=torch.float32, device=dev)
+    with pytest.raises(hip.GppError):
+        C.run_conv(C.conv_desc([x], [o], w, None, 1, 1, 48, 64, dtype='f32'))
+    x = C.FMap.empty(1, 4, 4, 64, torch.float32, dev)
+    w = torch.zeros((256, 64), dtype=torch.float32, device=dev)
+    d = C.conv_desc([x], [o], w, None, 1, 1, 64, 64, dtype='f32', diag=1)     # diagnostic bits: production library refuses
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -1
+    d16 = C.conv_desc([x], [o], w, None, 1, 1, 64, 64, dtype='f32')
+    assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d16), ctypes.byref(d16), 0, hip.stream_ptr()) == -4
+
+
+def test_f32_stem_pool_relu():
+    """ conv1 7x7/2 + folded bn + ReLU, 3x3/2 'same' max-pool and ReLU on float32 maps """
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 37, 53
+    img = (torch.rand((B, H, W, 3), generator=g) * 255.0 - 115.0)
+    k = torch.randn((7, 7, 3, 64), generator=g) * 0.01
+    bias = torch.randn((64,), generator=g) * 0.1
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    ref = torch.relu(F.conv2d(F.pad(img.double().permute(0, 3, 1, 2), (3, 3, 3, 3)), k.double().permute(3, 2, 0, 1), bias.double(), stride=2))
+    out = torch.full((B, Ho, Wo, 64), float('nan'), dtype=torch.float32, device=dev)
+    wd, img_d, bias_d = k.reshape(147, 64).contiguous().to(dev), img.to(dev).contiguous(), bias.to(dev)      # kept alive over the launch
+    hip.check(hip.lib().gpp_stem_conv7x7_bn_relu(hip.ptr(img_d), hip.ptr(wd), hip.ptr(bias_d), hip.ptr(out),
+                                                 hip.GPP_F32, B, H, W, hip.stream_ptr()), 'stem')
+    got = out.double().cpu().permute(0, 3, 1, 2)
+    assert bool(((got - ref).abs() <= 1e-5 * ref.abs() + 2e-5).all()), (got - ref).abs().max().item()
+    Hp, Wp = (Ho + 1) // 2, (Wo + 1) // 2
+    pooled = torch.full((B, Hp, Wp, 64), float('nan'), dtype=torch.float32, device=dev)
+    hip.check(hip.lib().gpp_maxpool3x3s2_same(hip.ptr(out), hip.ptr(pooled), hip.GPP_F32, B, Ho, Wo, 64, hip.stream_ptr()), 'pool')
+    pt = max((Hp - 1) * 2 + 3 - Ho, 0) // 2
+    pl = max((Wp - 1) * 2 + 3 - Wo, 0) // 2
+    xp = F.pad(out.cpu().permute(0, 3, 1, 2), (pl, 2, pt, 2), value=float('-inf'))
+    want = F.max_pool2d(xp, 3, 2)[:, :, :Hp, :Wp].permute(0, 2, 3, 1)
+    assert torch.equal(pooled.cpu(), want)
+    x = torch.randn((3, 40, 64), generator=g).to(dev)
+    y = torch.empty_like(x)
+    hip.check(hip.lib().gpp_relu(hip.ptr(x), hip.ptr(y), hip.GPP_F32, x.numel(), hip.stream_ptr()), 'relu')
+    assert torch.equal(y, torch.relu(x))
