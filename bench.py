@@ -2,7 +2,7 @@
 """
 bench.py -- images/sec end-to-end of the predict_on_batch path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|f16|f32]
     (N > 1: launched by the driver under torch.distributed.run, one rank per GPU)
 
 A step = one predict_on_batch-equivalent pass (ResNet-50 + FPN + heads + decode/NMS + ground-plane
@@ -11,12 +11,21 @@ the network input 402x1333 and resident in HBM (the reference's own timer, bin/r
 also starts after preprocessing).  N > 1: every rank runs its own 8 images (weak scaling, BASELINE
 config 3 = 64 images over 8 GPUs) and the step ends with ONE all-gather of the packed detections.
 
+`--dtype` is the storage AND operand type of the conv stack: bf16 (default) / f16 = 16-bit operands on
+v_mfma_f32_16x16x32_*, float32 accumulation; f32 = the reference's own arithmetic type (float32 operands on
+v_mfma_f32_16x16x4_f32, 1/16 of the 16-bit matrix rate).  Decode and polling are float32 / int32 in every mode.
+A 16-bit run on one GPU ALSO measures the float32 path on the same inputs (config.f32_images_per_s) and reports
+what the narrower storage type does to the final detections (config.parity_ledger: detection-set agreement,
+plane-index agreement, corner deviation against the float32 path; utils/ledger.py).
+
 The JSON line also carries
   roofline      the dominant kernel = conv_igemm_kernel on the 3x3 512->512 regression-tower layers
                 (45 % of all FLOPs): algorithmic FLOPs per launch / mean launch duration measured with
-                HIP events inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak
+                HIP events inside the timed region, against the dense MFMA peak of the operand type
   cpu_baseline  the CPU oracle (torch float32 restatement + NumPy decode + C polling) timed on this
-                host on a bounded sample -- "CPU restatement, not TF1" (TF1 cannot be installed)
+                host on a bounded sample -- "CPU restatement, not TF1" (TF1 cannot be installed); the same leg replays
+                decode + polling of the GPU's own head tensors of the last timed step and reports whether they agree
+                bit for bit (config.gpu_decode_polling_replay_bit_exact)
 """
 import argparse
 import json
@@ -31,7 +40,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 MEAN = np.array([103.939, 116.779, 123.68], np.float32)
-PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0}     # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (f32: v_mfma_f32_16x16x4_f32 / 32x32x2, = the vector rate)
+PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}
+PROFILE_ROUND = 'r2'
 
 
 def parse():
@@ -42,8 +53,10 @@ def parse():
     p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     p.add_argument('--backbone', default='resnet50')
     p.add_argument('--planes', default='1k')
-    p.add_argument('--dtype', default='bf16')
+    p.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-f32-leg', action='store_true', help='skip the float32 leg + parity ledger of a 16-bit run')
+    p.add_argument('--no-host-fed', action='store_true', help='skip the host-fed (PCIe-inclusive) legs')
     p.add_argument('--cpu-images', type=int, default=2)
     return p.parse_args()
 
@@ -61,8 +74,9 @@ def synthetic_batch(batch, rank):
     return out
 
 
-def cpu_baseline(n_images, backbone, planes):
-    """ whole path on the host cores with the oracle (bounded sample) """
+def cpu_baseline(n_images, backbone, planes, replay=None):
+    """ whole path on the host cores with the oracle (bounded sample); `replay` = the GPU's head tensors + outputs of
+    the last timed step (first images): decode + polling recomputed by the oracle must give the same bits """
     import torch
     from oracle import decode_np, net_torch
     from keras_retinanet_3D.models import weights as W
@@ -81,22 +95,52 @@ def cpu_baseline(n_images, backbone, planes):
     P_inv = P_inv[None].astype(np.float32)
     img = synthetic_batch(1, 0)
     net.forward(img[:, :64, :96])                    # warm the thread pool
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+
+    def poll(boxes, dims, orient, n):
+        kp = np.empty((n, 100, 4, 3), np.float32)
+        kpl = np.empty((n, 100, 1, 4), np.float32)
+        res = np.empty((n, 100), np.float32)
+        idx = np.empty((n, 100), np.int32)
+        pinv = np.ascontiguousarray(np.tile(P_inv, (n, 1, 1)))
+        lib.gpp_oracle_poll_f32(ptr(np.ascontiguousarray(boxes)), ptr(np.ascontiguousarray(dims)), ptr(np.ascontiguousarray(orient)),
+                                ptr(pinv), ptr(planes), n, 100, planes.shape[0], 0, ctypes.c_float(0.7), ptr(kp), ptr(kpl), ptr(res), ptr(idx))
+        return kp, kpl, res, idx
+
     t0 = time.perf_counter()
     for i in range(n_images):
         f = net.forward(synthetic_batch(1, 77 + i))
         det, _ = decode_np.detect(f['classification_logits'], f['regression'], f['regression_dim'], anchors)
-        boxes, dims, orient = det[0], det[1], det[4]
-        kp = np.empty((1, 100, 4, 3), np.float32)
-        kpl = np.empty((1, 100, 1, 4), np.float32)
-        res = np.empty((1, 100), np.float32)
-        idx = np.empty((1, 100), np.int32)
-        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-        lib.gpp_oracle_poll_f32(ptr(boxes), ptr(dims), ptr(orient), ptr(P_inv), ptr(planes), 1, 100, planes.shape[0], 0,
-                                ctypes.c_float(0.7), ptr(kp), ptr(kpl), ptr(res), ptr(idx))
+        poll(det[0], det[1], det[4], 1)
     dt = time.perf_counter() - t0
-    return {'value': round(n_images / dt, 4), 'unit': 'images/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-            'sample': '{} synthetic 402x1333 frames, batch 1, whole path (torch-CPU float32 conv stack + NumPy decode/NMS + '
-                      'C polling, {} planes); CPU restatement, not TF1'.format(n_images, planes.shape[0])}
+    rec = {'value': round(n_images / dt, 4), 'unit': 'images/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+           'sample': '{} synthetic 402x1333 frames, batch 1, whole path (torch-CPU float32 conv stack + NumPy decode/NMS + '
+                     'C polling, {} planes); CPU restatement, not TF1'.format(n_images, planes.shape[0])}
+    exact = None
+    if replay is not None:
+        n = replay['cls'].shape[0]
+        det, aidx = decode_np.detect(replay['cls'], replay['reg'], replay['dim'], anchors)
+        exact = all(np.array_equal(a, b) for a, b in zip(det, replay['out'][:5])) and np.array_equal(aidx, replay['anchor_index'])
+        kp, kpl, res, idx = poll(replay['out'][0], replay['out'][1], replay['out'][4], n)
+        same = lambda a, b: bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))  # noqa: E731
+        exact = bool(exact and np.array_equal(idx, replay['plane_index']) and same(kp, replay['out'][5]) and
+                     same(kpl, replay['out'][6]) and same(res, replay['out'][7]))
+    return rec, exact
+
+
+def unfuse(reg, n_base=12):
+    """ fused conv layout (B, P, 144) -> reference layout (B, A, 12) """
+    B, P, _ = reg.shape
+    op1 = reg[:, :, :4 * n_base].reshape(B, P, n_base, 4)
+    rest = [reg[:, :, 4 * n_base + 2 * n_base * k: 4 * n_base + 2 * n_base * (k + 1)].reshape(B, P, n_base, 2) for k in range(4)]
+    return np.concatenate([op1] + rest, axis=3).reshape(B, P * n_base, 12)
+
+
+def tile_name(code):
+    if not code:
+        return 'library heuristic'
+    bm, bn = (code // 1000) % 1000, code % 1000
+    return '{}x{}{}'.format(bm, bn, ' pipelined' if code >= 1000000 else '') if code < 2000000 else '256x256 + 512x128 dual grid'
 
 
 def main():
@@ -107,7 +151,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     force_dist = os.environ.get('GPP_BENCH_FORCE_DIST') == '1'      # exercise the RCCL path on a single GPU
-    if world > 1 or force_dist:
+    distributed = world > 1 or force_dist
+    if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -120,6 +165,7 @@ def main():
     from keras_retinanet_3D.backend import hip
     from keras_retinanet_3D.utils import synthetic
     from keras_retinanet_3D.utils import distributed as D
+    from keras_retinanet_3D.utils import ledger
     import ctypes
 
     model = models.load_model('synthetic:1234', backbone_name=args.backbone, dtype=args.dtype)
@@ -145,7 +191,7 @@ def main():
     def step(k=None):
         ev = None if k is None else [e.value for e in events[2 * n_tagged * k: 2 * n_tagged * (k + 1)]]
         model.run_plan(plan, ev)
-        if not (world > 1 or force_dist):
+        if not distributed:
             return None                                          # the eight result arrays are the plan's output buffers
         packed = D.pack_outputs(model.outputs(plan))             # one launch (gpp_pack_detections): what the ranks exchange
         while pending:
@@ -158,7 +204,7 @@ def main():
         out = step()
     while pending:
         pending.pop().wait()
-    if world > 1 or force_dist:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -167,14 +213,16 @@ def main():
     while pending:
         pending.pop().wait()                                   # the last gather completes inside the timed region
     torch.cuda.synchronize()
-    if world > 1 or force_dist:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1 or force_dist:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    gathered_images = int(out.shape[0]) if out is not None else B
+    rccl_world = dist.get_world_size() if distributed else 1
 
     # dominant kernel: mean launch duration from the HIP events recorded inside the timed region
     durations = []
@@ -206,24 +254,66 @@ def main():
                    'valu_tflops': round(poll_flops / (poll_ms * 1e-3) / 1e12, 2),
                    'frac_of_fp32_vector_peak': round(poll_flops / (poll_ms * 1e-3) / 157.3e12, 4),
                    'note': 'latency / VALU bound (exact IEEE divide + sqrt per pair), not HBM bound: the whole input is 16*N + 13600 bytes per image'}
-    # HBM/fabric traffic of that kernel cannot be read live (PMC needs rocprofv3): report the committed
-    # measurement of the same kernel on the same workload (profiles/r1/dominant_kernel_pmc.*, tools/pmc_bench.sh)
-    traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r1', 'dominant_kernel_pmc.json')
+    # HBM/fabric traffic of that kernel cannot be read live (PMC needs rocprofv3): report the committed measurement of the
+    # same kernel on the same workload (profiles/<round>/dominant_kernel_pmc.json, tools/pmc_bench.sh) -- but ONLY when it
+    # was collected with this very build of the library (gpp_version() carries a hash of the kernel sources)
+    traffic, traffic_note = None, None
+    version = lib.gpp_version().decode()
+    pmc_path = os.path.join(ROOT, 'profiles', PROFILE_ROUND, 'dominant_kernel_pmc.json')
     if os.path.isfile(pmc_path) and args.backbone == 'resnet50' and B == 8 and args.dtype == 'bf16':
         with open(pmc_path) as f:
-            traffic = round(json.load(f)['traffic_bytes_per_launch'] / 1e6, 1)
+            pmc = json.load(f)
+        if pmc.get('library_version') == version:
+            traffic = round(pmc['traffic_bytes_per_launch'] / 1e6, 1)
+        else:
+            traffic_note = 'omitted: {} was collected with "{}", this build is "{}"'.format(
+                os.path.relpath(pmc_path, ROOT), pmc.get('library_version'), version)
     counts = plan.counts.cpu().numpy()
     if out is None:
         out = D.pack_outputs(model.outputs(plan))
     dets = int((out[:, :, 15] > 0.05).sum().item())
+    extras = rank == 0 and world == 1
+
+    # outputs + head tensors of the last timed step (host copies): the ledger's run under test, the oracle's replay input
+    main_outs = [t.cpu().numpy() for t in model.outputs(plan)]
+    main_anchor, main_plane = plan.anchor_index.cpu().numpy(), plan.best_index.cpu().numpy()
+    replay = None
+    if extras and not args.no_cpu_baseline:
+        nrep = min(2, B)
+        replay = {'cls': plan.cls_logits[:nrep].cpu().numpy().reshape(nrep, -1, 8), 'reg': unfuse(plan.regression[:nrep].cpu().numpy()),
+                  'dim': plan.regression_dim[:nrep].cpu().numpy().reshape(nrep, -1, 3), 'out': [o[:nrep] for o in main_outs],
+                  'anchor_index': main_anchor[:nrep], 'plane_index': main_plane[:nrep]}
+
+    # ---- the float32 (reference-precision) leg of a 16-bit run + the parity ledger between the two
+    f32_rate = f32_ms = f32_tflops = None
+    parity = None
+    if extras and args.dtype != 'f32' and not args.no_f32_leg:
+        model32 = models.load_model('synthetic:1234', backbone_name=args.backbone, dtype='f32')
+        plan32 = model32.stage_inputs([images, P_inv_d, planes_d])
+        for _ in range(2):
+            model32.run_plan(plan32)
+        torch.cuda.synchronize()
+        n32 = 4
+        t1 = time.perf_counter()
+        for _ in range(n32):
+            model32.run_plan(plan32)
+        torch.cuda.synchronize()
+        dt32 = time.perf_counter() - t1
+        f32_rate, f32_ms = round(B * n32 / dt32, 2), round(1e3 * dt32 / n32, 3)
+        f32_tflops = round(plan32.flops * n32 / dt32 / 1e12, 1)
+        outs32 = [t.cpu().numpy() for t in model32.outputs(plan32)]
+        parity = ledger.parity_ledger(outs32, plan32.anchor_index.cpu().numpy(), plan32.best_index.cpu().numpy(),
+                                      main_outs, main_anchor, main_plane)
+        parity['what'] = '{} HIP path vs float32 HIP path, same {} frames, same weights'.format(args.dtype, B)
+        del model32, plan32
+        torch.cuda.empty_cache()
 
     # informational, outside the timed region and never `value`: the same step fed from HOST memory --
-    # raw uint8 frames uploaded over PCIe, preprocessed on the GPU, 8 result arrays copied back
+    # raw uint8 frames uploaded over PCIe, preprocessed on the GPU, results copied back
     pcie_rate = None
     pcie_pipelined = None
     host_fed_detections = None
-    if rank == 0 and world == 1:
+    if extras and not args.no_host_fed:
         # binary noise keeps its contrast through the bilinear resize, so decode / NMS / polling see candidates here
         # too (uniform noise is smoothed to nothing by the resize and would make this leg's decode free)
         frames = (np.random.default_rng(5).integers(0, 2, size=(B, 375, 1242, 3)) * 255).astype(np.uint8)
@@ -235,23 +325,24 @@ def main():
         host_fed_detections = int((np.asarray(host_out[0][2]) > 0.05).sum())          # scores of the 8 reference outputs
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        n_it = 10
+        n_it = 10 if args.dtype != 'f32' else 3
         for _ in range(n_it):
             model.predict_on_frames(frames, P_host, planes_host)
         torch.cuda.synchronize()
         pcie_rate = round(B * n_it / (time.perf_counter() - t1), 1)
         from keras_retinanet_3D.utils.pipeline import FramePipeline
-        pipe = FramePipeline(model, depth=2)
-        list(pipe.run(iter([(frames, P_host, planes_host)] * 3)))
+        pipe = FramePipeline(model)
+        list(pipe.run(iter([(frames, P_host, planes_host)] * 4)))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        n_it = 20
+        n_it = 30 if args.dtype != 'f32' else 4
         for _ in pipe.run(iter([(frames, P_host, planes_host)] * n_it)):
             pass
         pcie_pipelined = round(B * n_it / (time.perf_counter() - t1), 1)
 
     if rank == 0:
         total_images = world * B * args.steps
+        reg_tile = getattr(plan, 'tuning', {}).get('pyramid_regression_1', (0, 0.0))[0]
         rec = {
             'metric': 'images/sec end-to-end ({}, {} planes, 1242x375)'.format(args.backbone, args.planes),
             'value': round(total_images / elapsed, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
@@ -260,28 +351,45 @@ def main():
             'config': {'workload': 'batch={} synthetic 1242x375 frames per GPU (network input 402x1333, resident in HBM), '
                                    '{} + FPN + heads + decode/NMS + polling, {}-plane database ({} planes), seeded random weights'.format(
                                        B, args.backbone, args.planes, planes.shape[0]),
+                       'arithmetic': {'bf16': 'bf16 storage + operands, float32 accumulation', 'f16': 'f16 storage + operands, float32 accumulation',
+                                      'f32': 'float32 storage + operands + accumulation (the reference\'s floatx)'}[args.dtype] +
+                                     '; decode / NMS / polling float32 + int32',
                        'global_batch': world * B, 'parallelism': 'dp{} image shards, one all_gather of (B,100,35) f32'.format(world),
+                       'rccl_world_size': rccl_world, 'gathered_images_per_step': gathered_images,
                        'candidates_per_image': [int(c) for c in counts], 'detections_rank0': dets,
                        'algorithmic_gflop_per_image': round(plan.flops / B / 1e9, 1),
                        'achieved_tflops_whole_path': round(plan.flops * args.steps / elapsed / 1e12, 1),
+                       'frac_of_mfma_peak_whole_path': round(plan.flops * args.steps / elapsed / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                       'f32_images_per_s': f32_rate, 'f32_ms_per_step': f32_ms, 'f32_achieved_tflops_whole_path': f32_tflops,
+                       'f32_frac_of_f32_mfma_peak': None if f32_tflops is None else round(f32_tflops / PEAK_TFLOPS['f32'], 4),
+                       'parity_ledger': parity,
                        'host_fed_images_per_s_incl_pcie_and_gpu_preprocessing': pcie_rate,
-                       'host_fed_images_per_s_pipelined_uploads': pcie_pipelined, 'host_fed_detections': host_fed_detections,
+                       'reference_timer_images_per_s': pcie_pipelined,
+                       'reference_timer_note': 'feed + run + fetch as bin/run_network.py:108-111 brackets them, streaming form: uint8 frames '
+                                               'uploaded by a copy stream, GPU preprocessing, plan, one packed (B,100,35) D2H per batch',
+                       'host_fed_detections': host_fed_detections,
                        'polling_kernel': polling},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': traffic,
                          'traffic_unit': 'MB per launch at the L2<->fabric interface (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
                                          'algorithmic 192.1 MB)',
-                         'kernel': 'conv_igemm_kernel<{},256,256,2,4,2> on pyramid_regression_1..3 (3x3, 512->512, 5 levels, M={})'.format(
-                             args.dtype, B * (plan.n_anchors // 12)),
+                         'kernel': 'conv_igemm_kernel<{}> tile {} on pyramid_regression_1..3 (3x3, 512->512, 5 levels, M={})'.format(
+                             args.dtype, tile_name(reg_tile), B * (plan.n_anchors // 12)),
                          'gflop_per_launch': round(flops_per_launch / 1e9, 1), 'mean_launch_ms': round(mean_ms, 4),
-                         'launches_timed': len(durations)},
+                         'launches_timed': len(durations), 'library': version},
         }
+        if traffic_note:
+            rec['roofline']['traffic_note'] = traffic_note
         if world == 1 and not args.no_cpu_baseline:
-            rec['cpu_baseline'] = cpu_baseline(args.cpu_images, args.backbone, planes)
+            rec['cpu_baseline'], exact = cpu_baseline(args.cpu_images, args.backbone, planes, replay)
+            rec['config']['gpu_decode_polling_replay_bit_exact'] = exact
+            if exact is False:
+                print(json.dumps(rec))
+                raise SystemExit('decode / polling of the GPU head tensors differ from the oracle replay')
         print(json.dumps(rec))
     for e in events:
         lib.gpp_event_destroy(e)
-    if world > 1 or force_dist:
+    if distributed:
         dist.destroy_process_group()
 
 

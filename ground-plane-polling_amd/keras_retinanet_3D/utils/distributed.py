@@ -8,7 +8,10 @@ layers/filter_detections.py:257-262; polling is per (image, detection)): rank r 
 the contiguous images [r*B/W, (r+1)*B/W), weights and the plane database are replicated, and the
 only exchange is ONE all-gather of the packed final detections, 100 x 35 float32 = 14 000 bytes per
 image (RCCL over xGMI under torch.distributed backend 'nccl'; latency-bound at this size).
-No reduction takes place, so the gathered result is bit-identical to a single-GPU run.
+No reduction takes place, and every bit of an image's result is a function of (image, weights, dtype) alone -- block tiles
+are tuned per process but never change a result, split-K follows a rule of the layer alone (include/gpp.h,
+gpp_conv2d_split_rule) -- so the gathered result is bit-identical to a single-GPU run of the whole batch
+(tests/test_sharded_gpu.py: two processes with the real model against one process, byte for byte).
 """
 
 import numpy as np
@@ -68,12 +71,13 @@ def gather_detections(packed_local, shard_sizes=None, group=None, async_op=False
     if async_op:
         raise ValueError('async gather needs equal shards on the nccl (RCCL) backend')
     pad = max(shard_sizes)
-    local = packed_local
+    device = packed_local.device
+    local = packed_local.cpu() if dist.get_backend(group) == 'gloo' else packed_local      # gloo exchanges host tensors
     if local.shape[0] < pad:
         local = torch.cat([local, local.new_zeros((pad - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
     chunks = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(chunks, local.contiguous(), group=group)
-    return torch.cat([c[:n] for c, n in zip(chunks, shard_sizes)], dim=0)
+    return torch.cat([c[:n] for c, n in zip(chunks, shard_sizes)], dim=0).to(device)
 
 
 class ShardedModel(object):

@@ -10,20 +10,30 @@ the same loop.  Results are bit-identical to model.predict_on_frames called batc
 import numpy as np
 
 from ..backend import hip
+from . import distributed as D
 
 
 class FramePipeline(object):
-    """ pipeline = FramePipeline(model, batch, frame_shape, n_planes); for out in pipeline.run(batches): ...
+    """ pipeline = FramePipeline(model); for outs, scale in pipeline.run(batches): ...
 
     `batches` yields (frames_u8 (B, H, W, 3), P_inv (B, 4, 3), planes (B, N, 4) or (N, 4)); `run` yields the
-    list of 8 NumPy output arrays per batch, in order. """
+    list of 8 NumPy output arrays per batch (+ the resize scale), in order.
 
-    def __init__(self, model, depth=2):
+    Three things overlap with the kernels of batch k: the upload of batch k+1 (uploader thread + copy stream), the host-side
+    enqueue of batch k+1 (the host runs one batch ahead: it only waits for batch k-1's results), and the download of batch
+    k-1 (ONE (B, 100, 35) float32 tensor written by gpp_pack_detections at the end of each plan run, 14 KB per image, copied
+    by a second stream into pinned memory).  That is what the reference's timer brackets -- feed + run + fetch,
+    bin/run_network.py:108-111 -- in its streaming form; the compute stream never waits for the host. """
+
+    def __init__(self, model, depth=3, graph=False, pinned=True):
         import torch
         self.model = model
         self.torch = torch
-        self.depth = int(depth)
+        self.depth = max(2, int(depth))
+        self.graph = bool(graph)              # replay the plan as one HIP graph launch (model.capture) instead of ~95 launches
+        self.pinned = bool(pinned)
         self.copy_stream = torch.cuda.Stream()
+        self.down_stream = torch.cuda.Stream()
         self.slots = None
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(max_workers=1)
@@ -32,19 +42,23 @@ class FramePipeline(object):
         torch = self.torch
         dev = self.model.device
         self.slots = []
+        B = int(frames.shape[0])
         for _ in range(self.depth):
             self.slots.append({
                 'd_frames': torch.empty(tuple(frames.shape), dtype=torch.uint8, device=dev),
                 'd_pinv': torch.empty(tuple(P_inv.shape), dtype=torch.float32, device=dev),
                 'd_planes': torch.empty(tuple(planes.shape), dtype=torch.float32, device=dev),
+                'd_packed': torch.empty((B, 100, D.PACK_WIDTH), dtype=torch.float32, device=dev),
+                'h_packed': torch.empty((B, 100, D.PACK_WIDTH), dtype=torch.float32).pin_memory() if self.pinned else None,
                 'uploaded': torch.cuda.Event(), 'consumed': torch.cuda.Event(), 'done': torch.cuda.Event(),
+                'downloaded': torch.cuda.Event(),
             })
 
     def _upload(self, slot, frames, P_inv, planes):
         """ Runs on the uploader thread.  The copies come straight from the caller's (pageable) arrays through the
         HIP runtime's own staging buffers: they block this thread only (the GIL is released) while the main thread
-        waits for the GPU.  (Staging through torch pinned tensors was tried first: re-writing a pinned buffer on the
-        CPU and DMA-ing it again stalled the stream for ~85 ms every few batches on this platform.) """
+        enqueues kernels.  (Staging the FRAMES through torch pinned tensors was tried first: re-writing a pinned buffer on
+        the CPU and DMA-ing it again stalled the stream for ~85 ms every few batches on this platform.) """
         torch = self.torch
         torch.cuda.set_device(self.model.device)
         with torch.cuda.stream(self.copy_stream):
@@ -58,36 +72,47 @@ class FramePipeline(object):
         torch = self.torch
         cur = torch.cuda.current_stream()
         cur.wait_event(slot['uploaded'])
+        cur.wait_event(slot['downloaded'])                         # d_packed of this slot has been fetched
         plan, scale = self.model.stage_frames(slot['d_frames'], slot['d_pinv'], slot['d_planes'])
         slot['consumed'].record(cur)
+        if self.graph and getattr(plan, 'graph', None) is None:
+            self.model.capture(plan)
         self.model.run_plan(plan)
-        outs = self.model.outputs(plan)
-        slot['outs'] = outs
+        outs = self.model.outputs(plan)                            # the plan's buffers: the next batch overwrites them,
+        hip.check(hip.lib().gpp_pack_detections(*([hip.ptr(o) for o in outs] +     # so the results leave through the slot
+                                                  [int(outs[0].shape[0]), int(outs[0].shape[1]), hip.ptr(slot['d_packed']),
+                                                   hip.stream_ptr()])), 'gpp_pack_detections')
         slot['done'].record(cur)
+        if self.pinned:
+            with torch.cuda.stream(self.down_stream):
+                self.down_stream.wait_event(slot['done'])
+                slot['h_packed'].copy_(slot['d_packed'], non_blocking=True)
+                slot['downloaded'].record(self.down_stream)
         slot['scale'] = scale
 
     def run(self, batches):
-        """ Only ONE batch of kernels is in flight at a time (the HIP runtime was seen to block the host for
-        ~85 ms once a few hundred launches are queued); what overlaps with the GPU work of batch k is the upload
-        of batch k+1 on the copy stream and the host-side preparation of its arguments. """
-        prev = None
+        pending = []                    # launched, not yet yielded (oldest first); at most depth - 1 of them
         k = 0
         for frames, P_inv, planes in batches:
             if self.slots is None:
                 self._make_slots(np.asarray(frames), np.asarray(P_inv), np.asarray(planes))
                 for s in self.slots:
                     s['consumed'].record(self.torch.cuda.current_stream())
+                    s['downloaded'].record(self.torch.cuda.current_stream())
+            if len(pending) >= self.depth - 1:
+                yield self._collect(pending.pop(0))                 # frees the slot the upload below reuses
             slot = self.slots[k % self.depth]
-            fut = self.pool.submit(self._upload, slot, frames, P_inv, planes)   # overlaps the kernels of the previous batch
-            if prev is not None:
-                yield self._collect(prev)                           # host waits for the previous batch here
+            fut = self.pool.submit(self._upload, slot, frames, P_inv, planes)   # overlaps the kernels already in flight
             fut.result()
             self._launch(slot)
-            prev = slot
+            pending.append(slot)
             k += 1
-        if prev is not None:
-            yield self._collect(prev)
+        while pending:
+            yield self._collect(pending.pop(0))
 
     def _collect(self, slot):
-        slot['done'].synchronize()
-        return [o.cpu().numpy() for o in slot['outs']], slot['scale']
+        if not self.pinned:
+            slot['done'].synchronize()
+            return D.unpack_outputs(slot['d_packed'].cpu().numpy()), slot['scale']
+        slot['downloaded'].synchronize()
+        return D.unpack_outputs(slot['h_packed'].numpy().copy()), slot['scale']

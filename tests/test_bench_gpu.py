@@ -31,3 +31,24 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cpu['kind'] == 'port' and cpu['cores'] >= 1 and cpu['value'] > 0 and 'sample' in cpu
     poll = rec['config']['polling_kernel']
     assert poll['planes'] == 1000 and poll['launch_us'] > 0 and 0 < poll['frac_of_hbm_peak'] < 0.01
+    cfg = rec['config']
+    # the reference-precision leg and the ledger of the 16-bit path against it, measured by the same run
+    assert cfg['f32_images_per_s'] > 20 and 0.2 < cfg['f32_frac_of_f32_mfma_peak'] < 1.0
+    led = cfg['parity_ledger']
+    assert led['images'] == 8 and led['detections_ref'] > 400 and 0.0 < led['detection_set_agreement'] <= 1.0
+    assert 0.0 < led['plane_index_agreement'] <= 1.0
+    assert cfg['gpu_decode_polling_replay_bit_exact'] is True
+    assert cfg['reference_timer_images_per_s'] > 0.5 * rec['value'] and cfg['rccl_world_size'] == 1
+    assert roof['library'].startswith('gpp-hip') and 'src:' in roof['library']
+
+
+@pytest.mark.gpu
+def test_bench_at_reference_precision():
+    """ --dtype f32: the same JSON line for the float32 conv path, roofline against the float32 MFMA peak """
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--dtype', 'f32', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline', '--no-host-fed'],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert rec['dtype'] == 'f32' and rec['roofline']['peak'] == 157.3 and 0.3 < rec['roofline']['frac'] < 1.0
+    assert rec['value'] > 20 and rec['config']['parity_ledger'] is None and rec['roofline']['launches_timed'] == 6

@@ -80,7 +80,11 @@ def test_f32_path_matches_the_f32_oracle_end_to_end(f32_run, oracle_lib):
     assert led['detections_ref'] > 50
     assert led['detection_set_agreement'] == 1.0 and led['images_with_identical_detection_lists'] == 2, led
     assert led['orientation_agreement'] == 1.0 and led['plane_index_agreement'] == 1.0, led
-    assert led['max_keypoint_dev_m'] <= 1e-3 and led['max_corner_dev_m'] <= 1e-3 and led['max_box_diff_px'] <= 1e-2, led
+    # 3-D points: within 1e-3 m wherever the geometry is in the working range (<= 100 m); the random-weight "detections"
+    # whose rays graze the plane lie up to 10^6 m away -- there the bar is relative: 1e-4 of the distance
+    assert led['same_plane_within_100m'] >= 20, led
+    assert led['max_keypoint_dev_m_within_100m'] <= 1e-3 and led['max_corner_dev_m_within_100m'] <= 1e-3, led
+    assert led['max_keypoint_rel_dev'] <= 1e-4 and led['max_box_diff_px'] <= 1e-2, led
     # and decode + polling of the GPU's OWN float32 head tensors are bit-exact (the integer / op-by-op stages)
     det_g, _ = decode_np.detect(r['heads']['classification_logits'], r['heads']['regression'], r['heads']['regression_dim'], anchors)
     for got, want in zip(r['out'][:5], det_g):
@@ -111,7 +115,7 @@ def test_parity_ledger_of_the_16_bit_paths(dtype, f32_run):
     print('{} HIP vs f32 HIP:'.format(dtype), led)
     for key, bar in LEDGER_BARS[dtype].items():
         assert led[key] >= bar, (key, led)
-    assert led['common'] > 0 and np.isfinite(led['max_corner_dev_m_same_plane'])
+    assert led['common'] > 0 and np.isfinite(led['max_corner_rel_dev'])
 
 
 def test_conv_stack_at_402x1333_matches_the_storage_oracle():

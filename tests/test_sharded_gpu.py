@@ -1,0 +1,58 @@
+"""
+Multi-process run of the REAL model: two fresh child processes (subprocess, as the driver launches ranks; no exec of a
+GPU-initialised process), each computing its 2-image shard of a seeded 4-image batch at the BASELINE size 402x1333 with
+its own model instance -- its own block-tile tuning --, gathered over a gloo group; the parent computes the whole batch of
+4 in one process.  The gathered (4, 100, 35) tensor must equal the single-process result BYTE FOR BYTE: no reduction in
+the path, tiles never change a result, split-K is a rule of the layer alone (never of the batch size or the rank).
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+def test_two_process_shards_equal_the_single_process_batch(dtype, tmp_path):
+    import sharded_worker
+    from keras_retinanet_3D import models
+    batch, h, w = 4, 402, 1333
+    out_path = str(tmp_path / 'gathered.npy')
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'sharded_worker.py'), str(r), '2', str(port), str(batch),
+                               str(h), str(w), dtype, out_path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              universal_newlines=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=900)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), '\n'.join(l[-2000:] for l in logs)
+    gathered = np.load(out_path)
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype=dtype)
+    outs = model.predict_on_batch(list(sharded_worker.global_inputs(batch, h, w)))
+    single = np.concatenate([np.asarray(o, np.float32).reshape(batch, 100, -1) for o in outs], axis=2)
+    assert gathered.shape == single.shape == (batch, 100, 35)
+    assert (single[:, :, 15] > 0.05).sum() >= 40 * batch                 # real detections, not padding
+    assert gathered.tobytes() == single.tobytes()
+    # and each image alone (another plan, another batch size) gives the same bytes again
+    one = model.predict_on_batch([a[1:2] for a in sharded_worker.global_inputs(batch, h, w)])
+    alone = np.concatenate([np.asarray(o, np.float32).reshape(1, 100, -1) for o in one], axis=2)
+    assert alone.tobytes() == single[1:2].tobytes()
