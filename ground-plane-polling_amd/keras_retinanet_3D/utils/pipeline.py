@@ -25,11 +25,11 @@ class FramePipeline(object):
     by a second stream into pinned memory).  That is what the reference's timer brackets -- feed + run + fetch,
     bin/run_network.py:108-111 -- in its streaming form; the compute stream never waits for the host. """
 
-    def __init__(self, model, depth=3, graph=False, pinned=True):
+    def __init__(self, model, depth=4, graph=False, pinned=True):
         import torch
         self.model = model
         self.torch = torch
-        self.depth = max(2, int(depth))
+        self.depth = max(3, int(depth))
         self.graph = bool(graph)              # replay the plan as one HIP graph launch (model.capture) instead of ~95 launches
         self.pinned = bool(pinned)
         self.copy_stream = torch.cuda.Stream()
@@ -91,22 +91,35 @@ class FramePipeline(object):
         slot['scale'] = scale
 
     def run(self, batches):
-        pending = []                    # launched, not yet yielded (oldest first); at most depth - 1 of them
-        k = 0
-        for frames, P_inv, planes in batches:
+        """ Software pipeline over the batches: while batch k is being enqueued (and batches k-1, k-2 run on the GPU), the
+        uploader thread already copies batch k+1; results are yielded depth - 2 batches behind the enqueue. """
+        it = iter(batches)
+        pending = []                    # launched, not yet yielded (oldest first); at most depth - 2 of them
+        cap = self.depth - 2
+
+        def start_upload(k, item):
+            frames, P_inv, planes = item
             if self.slots is None:
                 self._make_slots(np.asarray(frames), np.asarray(P_inv), np.asarray(planes))
                 for s in self.slots:
                     s['consumed'].record(self.torch.cuda.current_stream())
                     s['downloaded'].record(self.torch.cuda.current_stream())
-            if len(pending) >= self.depth - 1:
-                yield self._collect(pending.pop(0))                 # frees the slot the upload below reuses
             slot = self.slots[k % self.depth]
-            fut = self.pool.submit(self._upload, slot, frames, P_inv, planes)   # overlaps the kernels already in flight
+            return slot, self.pool.submit(self._upload, slot, frames, P_inv, planes)
+
+        item = next(it, None)
+        k = 0
+        nxt = start_upload(k, item) if item is not None else None
+        while nxt is not None:
+            slot, fut = nxt
+            while len(pending) > cap:
+                yield self._collect(pending.pop(0))                 # frees the slot the next upload reuses
+            item = next(it, None)
+            k += 1
+            nxt = start_upload(k, item) if item is not None else None   # overlaps the enqueue below and the kernels in flight
             fut.result()
             self._launch(slot)
             pending.append(slot)
-            k += 1
         while pending:
             yield self._collect(pending.pop(0))
 

@@ -97,8 +97,9 @@ def test_f32_path_matches_the_f32_oracle_end_to_end(f32_run, oracle_lib):
 # bench line, config.parity_ledger): see DESIGN.md section 5.1.  Random weights are the hard case: a thousand candidates
 # per image sit within a few percent of each other in score, so 16-bit rounding reorders the top-100; trained weights
 # separate detections by orders of magnitude more.
-LEDGER_BARS = {'bf16': {'detection_set_agreement': 0.30, 'plane_index_agreement': 0.80},
-               'f16': {'detection_set_agreement': 0.60, 'plane_index_agreement': 0.90}}
+# measured (2 frames): bf16 0.905 / 0.932, f16 0.980 / 0.995; the bench line reports the same over 8 frames (bf16 0.916 / 0.895)
+LEDGER_BARS = {'bf16': {'detection_set_agreement': 0.80, 'plane_index_agreement': 0.85, 'orientation_agreement': 0.99},
+               'f16': {'detection_set_agreement': 0.95, 'plane_index_agreement': 0.97, 'orientation_agreement': 0.99}}
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'f16'])
@@ -131,7 +132,8 @@ def test_conv_stack_at_402x1333_matches_the_storage_oracle():
     for key in got:
         eq, ef = np.abs(got[key] - q[key]), np.abs(got[key] - f[key])
         scale = np.sqrt(((f[key] - f[key].mean()) ** 2).mean())
-        assert np.sqrt((eq ** 2).mean()) < 0.01 * scale and np.median(eq) < 0.01 and eq.max() < 0.15, (key, eq.max(), np.median(eq))
+        # (relative RMS measured at this size: 1.0 % on the regression head -- one bf16 ulp per element after ~60 layers)
+        assert np.sqrt((eq ** 2).mean()) < 0.0125 * scale and np.median(eq) < 0.01 and eq.max() < 0.15, (key, eq.max(), np.median(eq))
         assert np.sqrt((ef ** 2).mean()) < 0.015 * scale and ef.max() < 0.3, (key, ef.max())
 
 

@@ -39,9 +39,9 @@ for _ in range(n):
     model.predict_on_frames(frames, P, pl)
 torch.cuda.synchronize()
 print('predict_on_frames   %.1f images/s' % (B * n / (time.perf_counter() - t)))
-for graph in (False, True):
+for graph in (False,):
     for pinned in (True, False):
-        for depth in (2, 3, 4):
+        for depth in (3, 4, 5):
             pipe = FramePipeline(model, depth=depth, graph=graph, pinned=pinned)
             list(pipe.run(iter([(frames, P, pl)] * 4)))
             torch.cuda.synchronize()
