@@ -25,12 +25,16 @@ class FramePipeline(object):
     by a second stream into pinned memory).  That is what the reference's timer brackets -- feed + run + fetch,
     bin/run_network.py:108-111 -- in its streaming form; the compute stream never waits for the host. """
 
-    def __init__(self, model, depth=4, graph=False, pinned=True):
+    def __init__(self, model, depth=4, graph=False, pinned=False):
         import torch
         self.model = model
         self.torch = torch
         self.depth = max(3, int(depth))
-        self.graph = bool(graph)              # replay the plan as one HIP graph launch (model.capture) instead of ~95 launches
+        # measured on MI355X, 8 frames per batch (tools/pipe_variants.py): resident plan runs 1597 images/s; this pipeline 1525
+        # (95.5 %); with graph=True (the plan replayed as one HIP graph launch) 1100; with pinned=True (results copied into a
+        # pinned buffer by a third stream) 1097-1479 depending on depth -- re-used pinned host buffers stall this platform's
+        # DMA now and then, in either direction -- so both stay off
+        self.graph = bool(graph)
         self.pinned = bool(pinned)
         self.copy_stream = torch.cuda.Stream()
         self.down_stream = torch.cuda.Stream()

@@ -6,6 +6,13 @@ import json
 import sys
 
 src, out_prefix = sys.argv[1], sys.argv[2]
+# the library build the counters were collected with (bench.py prints it in roofline.library): bench.py only reports the
+# traffic figure when this matches the running library
+version = None
+for f in glob.glob(src + '/*.log'):
+    for line in open(f):
+        if line.startswith('{"metric"'):
+            version = json.loads(line)['roofline'].get('library', version)
 GRID = 722 * 512
 agg = collections.defaultdict(list)
 for f in glob.glob(src + '/*/**/*counter_collection.csv', recursive=True):
@@ -16,7 +23,7 @@ mean = {k: sum(v) / len(v) for k, v in agg.items()}
 read_b = 2.0 * mean['FETCH_SIZE'] * 1024
 write_b = mean['WRITE_SIZE'] * 1024
 alg_read, alg_write = 91504 * 512 * 2 + 512 * 4608 * 2, 91504 * 512 * 2
-lines = ['dominant kernel = conv_igemm_kernel<bf16,256,256,2,4,2,pipe>, grid 722 x 512 threads',
+lines = ['library: %s' % version, 'dominant kernel = conv_igemm_kernel<bf16,256,256,2,4,2,pipe>, grid 722 x 512 threads',
          '(regression tower 3x3 512->512 over the 5 pyramid levels, M = 91504 rows, B = 8)',
          'collected with tools/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline', '']
 for k in sorted(mean):
@@ -34,7 +41,7 @@ if 'SQ_VALU_MFMA_BUSY_CYCLES' in mean and 'GRBM_GUI_ACTIVE' in mean:
 if 'SQ_INSTS_VALU' in mean:
     lines.append('VALU instructions per MFMA = %.2f' % (mean['SQ_INSTS_VALU'] / mean['SQ_INSTS_MFMA']))
 open(out_prefix + '.txt', 'w').write('\n'.join(lines) + '\n')
-json.dump({'kernel': 'conv_igemm_kernel<bf16,256,256,2,4,2,pipe>', 'grid': GRID, 'traffic_bytes_per_launch': read_b + write_b,
+json.dump({'kernel': 'conv_igemm_kernel<bf16,256,256,2,4,2,pipe>', 'grid': GRID, 'library_version': version, 'traffic_bytes_per_launch': read_b + write_b,
            'read_bytes': read_b, 'write_bytes': write_b, 'algorithmic_bytes': alg_read + alg_write,
            'counters': mean}, open(out_prefix + '.json', 'w'), indent=1)
 print('\n'.join(lines))
