@@ -51,7 +51,18 @@ def test_two_process_shards_equal_the_single_process_batch(dtype, tmp_path):
     single = np.concatenate([np.asarray(o, np.float32).reshape(batch, 100, -1) for o in outs], axis=2)
     assert gathered.shape == single.shape == (batch, 100, 35)
     assert (single[:, :, 15] > 0.05).sum() >= 40 * batch                 # real detections, not padding
-    assert gathered.tobytes() == single.tobytes()
+    if gathered.tobytes() != single.tobytes():                            # say what differs before failing
+        d = np.abs(gathered.astype(np.float64) - single.astype(np.float64))
+        rows = np.argwhere(d.max(axis=2) > 0)
+        dump = os.path.join(ROOT, 'gpurun_out', 'sharded_mismatch_{}.npz'.format(dtype))
+        os.makedirs(os.path.dirname(dump), exist_ok=True)
+        outs2 = model.predict_on_batch(list(sharded_worker.global_inputs(batch, h, w)))       # which side moved?
+        second = np.concatenate([np.asarray(o, np.float32).reshape(batch, 100, -1) for o in outs2], axis=2)
+        np.savez(dump, gathered=gathered, single=single, second=second)
+        raise AssertionError('gathered != single: {} (image, detection) rows differ, first {}, columns {}, max |diff| {}; a second '
+                             'single-process run equals the first: {}, equals the gathered result: {}; arrays in {}'.format(
+                                 len(rows), rows[:5].tolist(), sorted(set(np.argwhere(d > 0)[:, 2].tolist())), d.max(),
+                                 second.tobytes() == single.tobytes(), second.tobytes() == gathered.tobytes(), dump))
     # and each image alone (another plan, another batch size) gives the same bytes again
     one = model.predict_on_batch([a[1:2] for a in sharded_worker.global_inputs(batch, h, w)])
     alone = np.concatenate([np.asarray(o, np.float32).reshape(1, 100, -1) for o in one], axis=2)
