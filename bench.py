@@ -41,7 +41,8 @@ import numpy as np  # noqa: E402
 
 MEAN = np.array([103.939, 116.779, 123.68], np.float32)
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (f32: v_mfma_f32_16x16x4_f32 / 32x32x2, = the vector rate)
-PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}
+# bf16x3: three bf16 matrix products per float32 product -> a third of the bf16 peak in float32-product FLOPs
+PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3.0}
 PROFILE_ROUND = 'r2'
 
 
@@ -53,7 +54,7 @@ def parse():
     p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     p.add_argument('--backbone', default='resnet50')
     p.add_argument('--planes', default='1k')
-    p.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    p.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32', 'bf16x3'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-f32-leg', action='store_true', help='skip the float32 leg + parity ledger of a 16-bit run')
     p.add_argument('--no-host-fed', action='store_true', help='skip the host-fed (PCIe-inclusive) legs')
@@ -291,29 +292,39 @@ def main():
                   'dim': plan.regression_dim[:nrep].cpu().numpy().reshape(nrep, -1, 3), 'out': [o[:nrep] for o in main_outs],
                   'anchor_index': main_anchor[:nrep], 'plane_index': main_plane[:nrep]}
 
-    # ---- the float32 (reference-precision) leg of a 16-bit run + the parity ledger between the two
-    f32_rate = f32_ms = f32_tflops = None
-    parity = None
-    if extras and args.dtype != 'f32' and not args.no_f32_leg:
-        model32 = models.load_model('synthetic:1234', backbone_name=args.backbone, dtype='f32')
-        plan32 = model32.stage_inputs([images, P_inv_d, planes_d])
+    # ---- the float32 (reference-precision) leg of a run at another type + the parity ledger against it; a default (bf16)
+    # run also measures the two other fast types on the same frames: f16 and bf16x3
+    def leg(dtype, n_timed):
+        m = models.load_model('synthetic:1234', backbone_name=args.backbone, dtype=dtype)
+        p = m.stage_inputs([images, P_inv_d, planes_d])
         for _ in range(2):
-            model32.run_plan(plan32)
+            m.run_plan(p)
         torch.cuda.synchronize()
-        n32 = 4
         t1 = time.perf_counter()
-        for _ in range(n32):
-            model32.run_plan(plan32)
+        for _ in range(n_timed):
+            m.run_plan(p)
         torch.cuda.synchronize()
-        dt32 = time.perf_counter() - t1
-        f32_rate, f32_ms = round(B * n32 / dt32, 2), round(1e3 * dt32 / n32, 3)
-        f32_tflops = round(plan32.flops * n32 / dt32 / 1e12, 1)
-        outs32 = [t.cpu().numpy() for t in model32.outputs(plan32)]
-        parity = ledger.parity_ledger(outs32, plan32.anchor_index.cpu().numpy(), plan32.best_index.cpu().numpy(),
-                                      main_outs, main_anchor, main_plane)
-        parity['what'] = '{} HIP path vs float32 HIP path, same {} frames, same weights'.format(args.dtype, B)
-        del model32, plan32
+        dt = time.perf_counter() - t1
+        res = {'images_per_s': round(B * n_timed / dt, 2), 'ms_per_step': round(1e3 * dt / n_timed, 3),
+               'achieved_tflops_whole_path': round(p.flops * n_timed / dt / 1e12, 1),
+               'frac_of_mfma_peak_whole_path': round(p.flops * n_timed / dt / 1e12 / PEAK_TFLOPS[dtype], 4)}
+        state = ([t.cpu().numpy() for t in m.outputs(p)], p.anchor_index.cpu().numpy(), p.best_index.cpu().numpy())
+        del m, p
         torch.cuda.empty_cache()
+        return res, state
+
+    f32_leg = None
+    parity = None
+    other_legs = {}
+    if extras and args.dtype != 'f32' and not args.no_f32_leg:
+        f32_leg, ref_state = leg('f32', 4)
+        parity = ledger.parity_ledger(*(ref_state + (main_outs, main_anchor, main_plane)))
+        parity['what'] = '{} HIP path vs float32 HIP path, same {} frames, same weights'.format(args.dtype, B)
+        if args.dtype == 'bf16':
+            for other in ('f16', 'bf16x3'):
+                res, state = leg(other, 8)
+                res['parity_ledger_vs_f32'] = ledger.parity_ledger(*(ref_state + state))
+                other_legs[other] = res
 
     # informational, outside the timed region and never `value`: the same step fed from HOST memory --
     # raw uint8 frames uploaded over PCIe, preprocessed on the GPU, results copied back
@@ -359,7 +370,8 @@ def main():
                                    '{} + FPN + heads + decode/NMS + polling, {}-plane database ({} planes), seeded random weights'.format(
                                        B, args.backbone, args.planes, planes.shape[0]),
                        'arithmetic': {'bf16': 'bf16 storage + operands, float32 accumulation', 'f16': 'f16 storage + operands, float32 accumulation',
-                                      'f32': 'float32 storage + operands + accumulation (the reference\'s floatx)'}[args.dtype] +
+                                      'f32': 'float32 storage + operands + accumulation (the reference\'s floatx)',
+                                      'bf16x3': 'float32 storage, every product as three bf16 matrix products (~2^-16 relative), float32 accumulation'}[args.dtype] +
                                      '; decode / NMS / polling float32 + int32',
                        'global_batch': world * B, 'parallelism': 'dp{} image shards, one all_gather of (B,100,35) f32'.format(world),
                        'rccl_world_size': rccl_world, 'gathered_images_per_step': gathered_images,
@@ -367,9 +379,12 @@ def main():
                        'algorithmic_gflop_per_image': round(plan.flops / B / 1e9, 1),
                        'achieved_tflops_whole_path': round(plan.flops * args.steps / elapsed / 1e12, 1),
                        'frac_of_mfma_peak_whole_path': round(plan.flops * args.steps / elapsed / 1e12 / PEAK_TFLOPS[args.dtype], 4),
-                       'f32_images_per_s': f32_rate, 'f32_ms_per_step': f32_ms, 'f32_achieved_tflops_whole_path': f32_tflops,
-                       'f32_frac_of_f32_mfma_peak': None if f32_tflops is None else round(f32_tflops / PEAK_TFLOPS['f32'], 4),
+                       'f32_images_per_s': None if f32_leg is None else f32_leg['images_per_s'],
+                       'f32_ms_per_step': None if f32_leg is None else f32_leg['ms_per_step'],
+                       'f32_achieved_tflops_whole_path': None if f32_leg is None else f32_leg['achieved_tflops_whole_path'],
+                       'f32_frac_of_f32_mfma_peak': None if f32_leg is None else f32_leg['frac_of_mfma_peak_whole_path'],
                        'parity_ledger': parity,
+                       'other_types_same_frames': other_legs or None,
                        'host_fed_images_per_s_incl_pcie_and_gpu_preprocessing': pcie_rate,
                        'reference_timer_images_per_s': pcie_pipelined,
                        'reference_timer_note': 'feed + run + fetch as bin/run_network.py:108-111 brackets them, streaming form: uint8 frames '

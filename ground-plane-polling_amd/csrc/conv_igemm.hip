@@ -13,12 +13,13 @@
 
 namespace {
 
-inline int elem_size(int dtype) { return dtype == GPP_F32 ? 4 : 2; }
+inline bool f32_storage(int dtype) { return dtype == GPP_F32 || dtype == GPP_BF16X3; }
+inline int elem_size(int dtype) { return f32_storage(dtype) ? 4 : 2; }
 
 int validate(const gpp_conv_desc& d)
 {
     if (!d.in || !d.weight || !d.out) return GPP_ERR_BAD_ARG;
-    if (d.dtype != GPP_BF16 && d.dtype != GPP_F16 && d.dtype != GPP_F32) return GPP_ERR_UNSUPPORTED;
+    if (d.dtype != GPP_BF16 && d.dtype != GPP_F16 && d.dtype != GPP_F32 && d.dtype != GPP_BF16X3) return GPP_ERR_UNSUPPORTED;
     const int esz = elem_size(d.dtype), ck = 128 / esz, va = 16 / esz;     // channels per K-step, elements per 16 bytes
     if (d.batch <= 0 || d.C_in <= 0 || d.C_out <= 0 || d.KH <= 0 || d.KW <= 0) return GPP_ERR_BAD_ARG;
     if (d.KH > 8 || d.KW > 8) return GPP_ERR_UNSUPPORTED;           // tap validity masks are 8 + 8 bits
@@ -29,7 +30,7 @@ int validate(const gpp_conv_desc& d)
 #ifndef GPP_STAMPS
     if (d.reserved != 0) return GPP_ERR_BAD_ARG;                    // diagnostic switches exist in -DGPP_STAMPS builds only
 #endif
-    const int oa = (d.out_f32 || d.dtype == GPP_F32) ? 4 : 8;        // output elements per 16 bytes
+    const int oa = (d.out_f32 || f32_storage(d.dtype)) ? 4 : 8;        // output elements per 16 bytes
     if (d.in_pitch < d.C_in || d.in_pitch % va != 0) return GPP_ERR_ALIGN;
     if (d.out_pitch < d.C_out || d.out_pitch % oa != 0) return GPP_ERR_ALIGN;
     if (d.residual && (d.res_pitch < d.C_out || d.res_pitch % va != 0)) return GPP_ERR_ALIGN;
@@ -69,6 +70,7 @@ int dispatch_any(gpp_conv_desc& d, hipStream_t st)
     switch (d.dtype) {
         case GPP_BF16: return gpp_conv_dispatch_bf16(d, st);
         case GPP_F16: return gpp_conv_dispatch_f16(d, st);
+        case GPP_BF16X3: return gpp_conv_dispatch_bf16x3(d, st);
         default: return gpp_conv_dispatch_f32(d, st);
     }
 }
@@ -82,7 +84,7 @@ int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const
     if (rc != GPP_OK) return rc;
     const gpp_conv_group &G1 = d1.groups[0], &G2 = d2.groups[0];
     // the pair this kernel fuses: 3x3 / stride 1 / pad 1 / C -> C (C = 64 or 128) feeding 1x1 / stride 1 / C -> multiple of 128
-    if (d1.dtype == GPP_F32) return GPP_ERR_UNSUPPORTED;            // 16-bit storage types only
+    if (f32_storage(d1.dtype)) return GPP_ERR_UNSUPPORTED;         // 16-bit storage types only
     if (d1.dtype != d2.dtype || d1.n_groups != 1 || d2.n_groups != 1 || d1.batch != d2.batch) return GPP_ERR_UNSUPPORTED;
     if (d1.KH != 3 || d1.KW != 3 || d1.stride != 1 || d1.pad_top != 1 || d1.pad_left != 1 || d1.residual || d1.out_f32) return GPP_ERR_UNSUPPORTED;
     if (d1.C_in != d1.C_out || (d1.C_in != 64 && d1.C_in != 128) || d1.weight_rows < d1.C_out) return GPP_ERR_UNSUPPORTED;
@@ -217,8 +219,8 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         const int bn = tile % 1000 ? tile % 1000 : 128;
         if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
         if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) continue;
-        if (tile > 1000000 && (nk < 4 || desc->dtype == GPP_F32)) continue;   // the pipelined loop needs a few K-steps to pay; 16-bit only
-        if (bn == 256 && desc->dtype == GPP_F32) continue;
+        if (tile > 1000000 && (nk < 4 || f32_storage(desc->dtype))) continue;   // the pipelined loop needs a few K-steps to pay; 16-bit only
+        if (bn == 256 && f32_storage(desc->dtype)) continue;
         if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding
         if (tile == 2256256 && (desc->C_out < 384 || desc->C_out % 256 != 128 || rows < 256 * 16)) continue;   // dual-shape grid: C_out = 256 k + 128
         float us = 0.0f;

@@ -236,6 +236,32 @@ __device__ __forceinline__ RowAddr row_addr(const gpp_conv_desc& d, int m, int H
     return a;
 }
 
+// float32 storage, three bf16 MFMAs per product (GPP_BF16X3): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (x - hi is
+// exact in float32), x * w ~ hi*whi + hi*wlo + lo*whi; the dropped lo*wlo term and the two roundings of lo leave a relative
+// error of about 2^-16 per product -- 2^8 closer to float32 than plain bf16 operands, at a third of the bf16 matrix rate.
+// Activations are split in registers on their way from LDS to the matrix pipe; weights are stored pre-split.
+template <> struct Elem<GPP_BF16X3> {
+    using scalar = float;
+    using vec8 = f32x8;
+    using frag = f32x4;
+    static constexpr int ESZ = 4;
+    static __device__ __forceinline__ vec8 pack(const float (&v)[8]) { return Elem<GPP_F32>::pack(v); }
+    static __device__ __forceinline__ f32x4 mfma(frag, frag, f32x4 c) { return c; }      // unused: the K-step has its own form
+    // 8 consecutive float32 K values -> their bf16 hi and lo parts (round to nearest even, v_cvt_pk_bf16_f32)
+    static __device__ __forceinline__ void split(const f32x4 x0, const f32x4 x1, bf16x8& hi, bf16x8& lo)
+    {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = e < 4 ? x0[e] : x1[e - 4];
+            const __bf16 h = (__bf16)x;
+            hi[e] = h;
+            lo[e] = (__bf16)(x - (float)h);
+        }
+    }
+};
+
+template <int DT> constexpr bool kF32Storage = (DT == GPP_F32 || DT == GPP_BF16X3);
+
 template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
 __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const int block_x, const int grid_x)
 {
@@ -347,6 +373,12 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         a_rd[kk] = (wm * (BM / WM) + frow) * kRowBytes + sw;
         b_rd[kk] = A_BYTES + (wn * (BN / WN) + frow) * kRowBytes + sw;
     }
+
+    // GPP_BF16X3: a lane's 8 consecutive float32 K values (8 fq .. 8 fq + 7 of the 32-channel K-step) are chunks 2 fq and
+    // 2 fq + 1 of the activation row; the weight row holds [32 bf16 hi | 32 bf16 lo], i.e. chunk fq and chunk 4 + fq = b_rd[0], b_rd[1]
+    int a_rdx[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a_rdx[h] = (wm * (BM / WM) + frow) * kRowBytes + (((2 * fq + h) ^ (frow & 7)) << 4);
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -548,11 +580,38 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         if (issued < nk) issue_next();
 #endif
         {
+            if constexpr (DT == GPP_BF16X3) {
+                // one 32-channel K-step = one k-slice of v_mfma_f32_16x16x32_bf16, three matrix products per accumulator:
+                // the two cross terms first, the dominant hi * hi term last
+                const unsigned char* sbase = smem + cbuf * STAGE;
+                bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                frag af[MF], bfr[NF];
-                load_frags(af, bfr, cbuf, kk);
-                mfma_all(af, bfr);
+                for (int i = 0; i < MF; ++i)
+                    Elem<GPP_BF16X3>::split(*(const f32x4*)(sbase + a_rdx[0] + i * 16 * kRowBytes),
+                                            *(const f32x4*)(sbase + a_rdx[1] + i * 16 * kRowBytes), ah[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    bh[j] = *(const bf16x8*)(sbase + b_rd[0] + j * 16 * kRowBytes);
+                    bl[j] = *(const bf16x8*)(sbase + b_rd[1] + j * 16 * kRowBytes);
+                }
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    frag af[MF], bfr[NF];
+                    load_frags(af, bfr, cbuf, kk);
+                    mfma_all(af, bfr);
+                }
             }
         }
         if (++cbuf == STAGES) cbuf = 0;
@@ -1058,7 +1117,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
 template <int BM, int BN>
 int prepare(gpp_conv_desc& d)
 {
-    const int esz = d.dtype == GPP_F32 ? 4 : 2;
+    const int esz = (d.dtype == GPP_F32 || d.dtype == GPP_BF16X3) ? 4 : 2;
     if (d.weight_rows < ((d.C_out + BN - 1) / BN) * BN) return GPP_ERR_BAD_ARG;
     int64_t in_elems = 0;
     for (int g = 0; g < d.n_groups; ++g) {
@@ -1183,7 +1242,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
         case 128:
         case 128128:
 #ifdef GPP_STAMPS
-            if constexpr (DT != GPP_F32) if (d.reserved & 4) return launch<DT, 128, 128, 2, 2, 2, true>(d, st);
+            if constexpr (!kF32Storage<DT>) if (d.reserved & 4) return launch<DT, 128, 128, 2, 2, 2, true>(d, st);
 #endif
             return launch<DT, 128, 128, 2, 2, 2, false>(d, st);
         case 160128: return launch<DT, 160, 128, 2, 2, 2, false>(d, st);
@@ -1198,7 +1257,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
         default:
             // the software-pipelined / 8-wavefront forms exist for the 16-bit types only: the float32 path is bound by the
             // matrix pipe (8x the MFMA time per staged byte) and gains nothing from them
-            if constexpr (DT != GPP_F32) {
+            if constexpr (!kF32Storage<DT>) {
                 switch (d.tile_hint) {
                     case 256: return launch<DT, 256, 128, 4, 2, 3, false>(d, st);          // 3-deep ring, experiments only
                     case 1128128: return launch<DT, 128, 128, 2, 2, 2, true>(d, st);        // 1000000 + ...: the pipelined main loop
@@ -1225,7 +1284,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
     }
     // ---- default heuristic (tile_hint == 0)
     if (d.C_out <= 64 || (d.C_out % 128 != 0 && d.C_out % 128 <= 64)) return launch<DT, 128, 64, 2, 2, 2, false>(d, st);
-    if constexpr (DT != GPP_F32) {
+    if constexpr (!kF32Storage<DT>) {
         // 256x256 tile (8 wavefronts, 1 workgroup / CU) halves the L2 -> LDS traffic per FLOP; it pays
         // when there are enough tiles for two rounds over the 256 CUs and enough K-steps to amortise
         // its longer prologue/epilogue

@@ -36,6 +36,7 @@ c_int64 = ctypes.c_int64
 GPP_BF16 = 1
 GPP_F16 = 2
 GPP_F32 = 3
+GPP_BF16X3 = 4
 GPP_MAX_GROUPS = 5
 
 

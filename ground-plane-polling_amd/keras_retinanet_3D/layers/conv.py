@@ -17,15 +17,21 @@ from ..backend import hip
 
 def torch_dtype(dtype):
     import torch
-    return {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtype]
+    return {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'bf16x3': torch.float32}[dtype]
 
 
 def gpp_dtype(dtype):
-    return {'bf16': hip.GPP_BF16, 'f16': hip.GPP_F16, 'f32': hip.GPP_F32}[dtype]
+    """ element / arithmetic type of the convolution kernels (include/gpp.h) """
+    return {'bf16': hip.GPP_BF16, 'f16': hip.GPP_F16, 'f32': hip.GPP_F32, 'bf16x3': hip.GPP_BF16X3}[dtype]
+
+
+def gpp_storage_dtype(dtype):
+    """ what the stem / pool / ReLU kernels see: 'bf16x3' stores float32 and only multiplies differently """
+    return hip.GPP_F32 if dtype in ('f32', 'bf16x3') else gpp_dtype(dtype)
 
 
 def elem_size(dtype):
-    return 4 if dtype == 'f32' else 2
+    return 4 if dtype in ('f32', 'bf16x3') else 2
 
 
 def k_chunk(dtype):
@@ -68,6 +74,13 @@ def pack_weight(kernel_hwio, dtype, device):
     # K order (chunk of CK input channels, kh, kw, CK channels): see include/gpp.h
     w[:Cout] = k.permute(3, 0, 1, 2).reshape(Cout, KH * KW, Cin // ck, ck).permute(0, 2, 1, 3).reshape(Cout, KH * KW * Cin)
     w = w[weight_row_order(rows)]
+    if dtype == 'bf16x3':
+        # every K-step of 32 channels becomes [32 bf16 hi | 32 bf16 lo], hi = bf16(w), lo = bf16(w - hi), both round-to-nearest:
+        # the same 128 bytes per row and K-step as float32, handed out as a float32-typed tensor of the usual shape
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+        both = torch.stack([hi.reshape(rows, -1, 32), lo.reshape(rows, -1, 32)], dim=2).reshape(rows, 2 * KH * KW * Cin)
+        return both.contiguous().view(torch.float32).to(device).contiguous()
     return w.to(torch_dtype(dtype)).to(device).contiguous()
 
 

@@ -46,7 +46,9 @@ def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, clas
 
     `convert` is accepted for signature compatibility: every model this function returns already
     contains the decode / NMS / ground-plane-polling stages (`retinanet_bbox`, retinanet.py:359-422).
-    `dtype` ('bf16' | 'f16') is the 16-bit storage type of activations and weights on the GPU.
+    `dtype`: 'bf16' (default) | 'f16' = 16-bit storage and MFMA operands, float32 accumulation; 'f32' = float32 storage
+    and operands (the reference's floatx, /root/reference/keras_retinanet_3D/utils/image.py:47); 'bf16x3' = float32 storage,
+    each product as three bf16 matrix products (~2^-16 relative error per product, three times the bf16 matrix work).
     """
     from . import weights as W
     from .retinanet import RetinaNet3D

@@ -17,7 +17,8 @@ hand-written kernels of ../csrc; PyTorch only owns the device buffers.
 
 HBM layout
   * activations NHWC, 16-bit (bf16 default, f16) or float32 (dtype='f32': the reference's own arithmetic type --
-    float32 operands on v_mfma_f32_16x16x4_f32, float32 stem, no fused bottleneck tails), one dense buffer per live tensor
+    float32 operands on v_mfma_f32_16x16x4_f32, float32 stem, no fused bottleneck tails; dtype='bf16x3': the same float32
+    storage with every float32 product computed as three bf16 matrix products, ~2^-16 relative), one dense buffer per live tensor
   * the five pyramid levels of every FPN / head tensor are stored back to back per image,
     (B, 11438, C) for a 402x1333 input, so that one grouped launch covers all levels and the head
     outputs come out directly in the reference's concatenated (B, A, k) order
@@ -129,8 +130,8 @@ class RetinaNet3D(object):
         self.backbone_name = backbone_name.split('_')[0]
         if self.backbone_name not in W.BLOCKS:
             raise ValueError('Backbone (\'{}\') not in allowed backbones ({}).'.format(backbone_name, sorted(W.BLOCKS)))
-        if dtype not in ('bf16', 'f16', 'f32'):
-            raise ValueError("dtype must be 'bf16', 'f16' or 'f32', got {!r}".format(dtype))
+        if dtype not in ('bf16', 'f16', 'f32', 'bf16x3'):
+            raise ValueError("dtype must be 'bf16', 'f16', 'f32' or 'bf16x3', got {!r}".format(dtype))
         self.dtype = dtype
         self.esz = C.elem_size(dtype)
         self.tdtype = C.torch_dtype(dtype)
@@ -158,7 +159,7 @@ class RetinaNet3D(object):
             if k.shape != (kh, kw, cin, cout):
                 raise ValueError('weight {} has shape {}, expected {}'.format(conv, k.shape, (kh, kw, cin, cout)))
             if conv == 'conv1':
-                if self.dtype == 'f32':      # float32 stem on the vector ALUs: the folded kernel as it is, [147][64]
+                if self.esz == 4:            # float32 stem on the vector ALUs: the folded kernel as it is, [147][64]
                     self.stem_w = torch.as_tensor(np.ascontiguousarray(k.reshape(147, 64), dtype=np.float32)).to(dev).contiguous()
                 else:
                     self.stem_w = hip.pack_stem_weights(k.reshape(147, 64), dev)
@@ -248,12 +249,12 @@ class RetinaNet3D(object):
         H1, W1 = (H + 6 - 7) // 2 + 1, (Wd + 6 - 7) // 2 + 1
         stem = fmap(H1, W1, 64)
         d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
-                     C.gpp_dtype(self.dtype), B, H, Wd)
+                     C.gpp_storage_dtype(self.dtype), B, H, Wd)
         plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
         plan.stem_out = stem
         H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
         x = fmap(H2, W2, 64)
-        plan.add(OP_MAXPOOL, PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_dtype(self.dtype), B, H1, W1, 64, 0), 'pool1')
+        plan.add(OP_MAXPOOL, PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_storage_dtype(self.dtype), B, H1, W1, 64, 0), 'pool1')
         plan.pool_out = x
 
         # ---- bottleneck stages (keras_resnet bottleneck_2d: stride on the first 1x1).
@@ -265,7 +266,7 @@ class RetinaNet3D(object):
         # whole step: none 1553, res3 only 1562, res2 + res3 1571 images/s (in isolation the fused res2 launch is no
         # faster than its two layers -- 122 us vs 36 + 80 -- but the step is: 69 MB less through HBM per block)
         fuse_tail = [int(v) for v in os.environ.get('GPP_FUSE_TAIL', '64,128').split(',') if v.strip() and int(v) > 0]
-        if self.dtype == 'f32':
+        if self.esz == 4:
             fuse_tail = []              # the fused tail keeps a 16-bit intermediate tile in LDS: 16-bit storage types only
 
         # GPP_FUSE_NEXT=1: additionally the first 1x1 layer of the FOLLOWING identity block in the same launch
@@ -346,7 +347,7 @@ class RetinaNet3D(object):
         self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]), lane=l_p6)
         R6 = fmap(shapes[3][0], shapes[3][1], 512)
         plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * self.esz, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
-                                   pix[3] * 512, C.gpp_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
+                                   pix[3] * 512, C.gpp_storage_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
         plan.relu_io = (P[3], R6)
         self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
                    pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]), lane=l_p6)
@@ -547,7 +548,7 @@ class RetinaNet3D(object):
                 continue
             key = (name, B, H, Wd)
             if key not in self._tuned:
-                iters = (2 if self.dtype == 'f32' else 4) if flops > 5e10 else (4 if self.dtype == 'f32' else 16)
+                iters = (2 if self.esz == 4 else 4) if flops > 5e10 else (4 if self.esz == 4 else 16)
                 hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(desc), iters, hip.stream_ptr(), ctypes.byref(best)),
                           'gpp_conv2d_autotune')
                 self._tuned[key] = (int(desc.tile_hint), round(float(best.value), 2))

@@ -75,6 +75,11 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
 #define GPP_F32 3    /* float32 storage AND float32 operands (v_mfma_f32_16x16x4_f32: every product rounded once, float32
                         accumulation): the arithmetic type of the reference, keras.backend.floatx() = float32
                         (utils/image.py:47, placeholders models/retinanet.py:395-396).  1/16 of the 16-bit MFMA rate. */
+#define GPP_BF16X3 4 /* float32 storage, each float32 product as three bf16 matrix products: x = hi + lo (hi = bf16(x), lo =
+                        bf16(x - hi)), x*w ~ hi*whi + hi*wlo + lo*whi, float32 accumulation: ~2^-16 relative error per product
+                        (float32: 2^-24, plain bf16 operands: 2^-8) at a third of the bf16 MFMA rate.  Activations, residuals
+                        and outputs are float32 exactly as for GPP_F32; the weight matrix holds, per K-step of 32 input
+                        channels, the 32 bf16 hi parts followed by the 32 bf16 lo parts (same bytes per row as float32). */
 
 /* ------------------------------------------------------------------------------------------
  * 2-D convolution, NHWC, implicit GEMM on MFMA (no im2col buffer), fused epilogue
@@ -88,10 +93,10 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
  * (the five pyramid levels of a head layer, retinanet.py:257-281), each described by a
  * gpp_conv_group.  GEMM view per group: M = batch*H_out*W_out output pixels, N = C_out,
  * K = KH*KW*C_in, K ordered (c_in / CK, kh, kw, c_in % CK) with CK = 128 bytes of channels (64 for the 16-bit types,
- * 32 for GPP_F32): the taps of one channel chunk are adjacent so that their overlapping input rows are re-read
+ * 32 for GPP_F32 / GPP_BF16X3): the taps of one channel chunk are adjacent so that their overlapping input rows are re-read
  * from the XCD-local L2.
  *
- * Layouts (element = 2 bytes for GPP_BF16 / GPP_F16, 4 bytes for GPP_F32)
+ * Layouts (element = 2 bytes for GPP_BF16 / GPP_F16, 4 bytes for GPP_F32 / GPP_BF16X3)
  *   in        pixel (b, y, x) of a group at  in + in_off + b*in_bstride + (y*W_in + x)*in_pitch,
  *             C_in contiguous channels there (in_pitch >= C_in lets a channel slice be read)
  *   weight    [C_out rounded up to a multiple of 256][KH*KW*C_in], K contiguous; rows >= C_out
@@ -130,7 +135,7 @@ typedef struct gpp_conv_desc {
     const void* residual;
     void* out;
     const void* zero_page;
-    int32_t dtype;                  /* GPP_BF16 | GPP_F16 | GPP_F32 */
+    int32_t dtype;                  /* GPP_BF16 | GPP_F16 | GPP_F32 | GPP_BF16X3 */
     int32_t out_f32;
     int32_t batch, C_in, C_out, KH, KW, stride, pad_top, pad_left;
     int32_t in_pitch, out_pitch, res_pitch;   /* elements per pixel */

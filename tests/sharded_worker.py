@@ -43,6 +43,15 @@ def main():
     if rank == 0:
         packed = np.concatenate([np.asarray(o, np.float32).reshape(batch, 100, -1) for o in outs], axis=2)
         np.save(out_path, packed)
+    debug = os.environ.get('GPP_SHARD_DEBUG_DIR')
+    if debug:                    # the polling stage's shared inputs and this rank's own outputs, as they are on the device
+        lo, hi = D.shard_range(batch, rank, world)
+        plan = model.plan_for(hi - lo, h, w, 1000, True)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(debug, 'rank{}.npz'.format(rank)), planes=plan.planes.cpu().numpy(),
+                 canon=plan.poll_ws.cpu().numpy().view(np.float32), P_inv=plan.P_inv.cpu().numpy(),
+                 boxes=plan.boxes.cpu().numpy(), dims=plan.dimensions.cpu().numpy(), orient=plan.orientations.cpu().numpy(),
+                 keypoints=plan.keypoints.cpu().numpy(), best=plan.best_index.cpu().numpy(), residuals=plan.residuals.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 

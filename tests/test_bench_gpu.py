@@ -37,6 +37,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     led = cfg['parity_ledger']
     assert led['images'] == 8 and led['detections_ref'] > 400 and 0.0 < led['detection_set_agreement'] <= 1.0
     assert 0.0 < led['plane_index_agreement'] <= 1.0
+    x3 = cfg['other_types_same_frames']['bf16x3']
+    assert x3['images_per_s'] > 200 and x3['parity_ledger_vs_f32']['detection_set_agreement'] >= led['detection_set_agreement']
+    assert cfg['other_types_same_frames']['f16']['images_per_s'] > 500
     assert cfg['gpu_decode_polling_replay_bit_exact'] is True
     assert cfg['reference_timer_images_per_s'] > 0.5 * rec['value'] and cfg['rccl_world_size'] == 1
     assert roof['library'].startswith('gpp-hip') and 'src:' in roof['library']

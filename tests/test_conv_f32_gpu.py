@@ -37,7 +37,7 @@ def reference64(x, k, bias, stride, pad_t, pad_l, oh, ow, relu, res):
     return torch.relu(y) if relu else y
 
 
-def _layer(case, seed_shift=0):
+def _layer(case, seed_shift=0, dtype='f32'):
     name, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, _ = case
     g = torch.Generator().manual_seed(sum(map(ord, name)) + seed_shift)
     dev = torch.device('cuda')
@@ -58,14 +58,14 @@ def _layer(case, seed_shift=0):
     ref = reference64(x, k, bias, stride, pt, pl, oh, ow, relu, res)
     xin = C.FMap(x.to(dev).contiguous(), B, H, W, Cin)
     out = C.FMap.empty(B, oh, ow, Cout, torch.float32, dev)
-    w = C.pack_weight(k.numpy(), 'f32', dev)
+    w = C.pack_weight(k.numpy(), dtype, dev)
     rmap = None if res is None else [C.FMap(res.to(dev).contiguous(), B, res.shape[1], res.shape[2], Cout)]
     ws = torch.empty((32 << 20,), dtype=torch.uint8, device=dev)
     keep = (xin, w, rmap, ws, bias.to(dev))
 
     def make(tile, split_k=1, workspace=False):
         return C.conv_desc([xin], [out], w, keep[4], K, K, Cin, Cout, stride=stride, pad=(pt, pl), relu=relu, residuals=rmap,
-                           dtype='f32', tile_hint=tile, workspace=ws if workspace else None, split_k=split_k)
+                           dtype=dtype, tile_hint=tile, workspace=ws if workspace else None, split_k=split_k)
     return make, out, ref, K * K * Cin, keep
 
 
@@ -108,6 +108,46 @@ def test_every_f32_tile_gives_identical_results(case):
             continue
         C.run_conv(d)
         assert torch.equal(out.buf, base), tile
+
+
+@pytest.mark.parametrize('tile', [0, 64064, 128128, 192128, 128160])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16x3_matches_float64_reference(case, tile):
+    """ GPP_BF16X3: float32 storage, x*w computed as hi*whi + hi*wlo + lo*whi on the bf16 matrix pipe.  Per product the
+    dropped lo*wlo term and the roundings of the lo parts leave ~2^-16 |x w|; over K random-sign terms that is about
+    1e-5 * rms(ref) -- bar: |err| <= 1e-4 * |ref| + 1e-4 * rms(ref)  (plain bf16 operands: 4e-3; float32: 1e-6). """
+    make, out, ref, kdepth, _ = _layer(case, dtype='bf16x3')
+    out.buf.fill_(float('nan'))
+    d = make(tile)
+    bn = tile % 1000 if tile else 64
+    if -(-d.C_out // bn) * bn > d.weight_rows:
+        pytest.skip('tile grid would read past the packed weight rows')
+    C.run_conv(d)
+    got = out.buf.double().cpu()
+    assert torch.isfinite(got).all()
+    rms = float(ref.pow(2).mean().sqrt())
+    err = (got - ref).abs()
+    assert bool((err <= 1e-4 * ref.abs() + 1e-4 * rms).all()), 'max err {} (rms {})'.format(err.max().item(), rms)
+    assert float(err.pow(2).mean().sqrt()) < 2e-5 * rms + 1e-7          # and ~100x closer than bf16 operands on average
+
+
+@pytest.mark.parametrize('case', ['3x3_wide', '1x1_res_up_nonint', 'head_out144_f32', '3x3_s2_tfsame', 'deepK'])
+def test_every_bf16x3_tile_gives_identical_results(case):
+    make, out, _, _, _ = _layer([c for c in CASES if c[0] == case][0], dtype='bf16x3')
+    C.run_conv(make(128128))
+    base = out.buf.clone()
+    for tile in F32_TILES:
+        out.buf.fill_(float('nan'))
+        d = make(tile)
+        if -(-d.C_out // (tile % 1000)) * (tile % 1000) > d.weight_rows:
+            continue
+        C.run_conv(d)
+        assert torch.equal(out.buf, base), tile
+    out.buf.fill_(float('nan'))
+    C.run_conv(make(96128, split_k=3, workspace=True))
+    first = out.buf.clone()
+    C.run_conv(make(192128, split_k=3, workspace=True))               # split-K: same summation order on every tile
+    assert torch.equal(out.buf, first)
 
 
 def test_pipelined_and_wide_tiles_are_16_bit_only():

@@ -337,7 +337,8 @@ def test_frame_pipeline_matches_synchronous_calls(model50):
 
 
 @pytest.mark.parametrize('backbone,dtype,fuse_next', [('resnet50', 'bf16', '0'), ('resnet101', 'f16', '0'), ('resnet152', 'bf16', '0'),
-                                                      ('resnet50', 'bf16', '1'), ('resnet50', 'f32', '0'), ('resnet101', 'f32', '0')])
+                                                      ('resnet50', 'bf16', '1'), ('resnet50', 'f32', '0'), ('resnet101', 'f32', '0'),
+                                                      ('resnet50', 'bf16x3', '0')])
 def test_every_layer_on_oracle_inputs(backbone, dtype, fuse_next, monkeypatch):
     check_every_layer(backbone, dtype, fuse_next, 2, 120, 200, monkeypatch)
 
@@ -350,7 +351,8 @@ def check_every_layer(backbone, dtype, fuse_next, batch, h, w, monkeypatch):
     float32; only the summation order differs, so a stored bf16 output may differ from the oracle's by
     one rounding step.  Tolerance: |gpu - oracle| <= ulp |oracle| + 1e-4 * rms (ulp 2^-7 bf16, 2^-10 f16) and
     >= 99 % of elements bit-equal; float32 maps (the head outputs, and EVERY map of the dtype='f32' reference-precision
-    path, whose oracle is the literal-BatchNormalization float32 graph): <= 2e-5 * rms + 1e-5 |oracle|.
+    path, whose oracle is the literal-BatchNormalization float32 graph): <= 2e-5 * rms + 1e-5 |oracle|; dtype='bf16x3'
+    (float32 storage, three bf16 products per float32 product) against the same float32 oracle: <= 2e-4 * rms + 1e-4 |oracle|.
     (tests/test_fullsize_gpu.py runs the same check at the BASELINE size 402x1333.) """
     import torch
     from keras_retinanet_3D.models.retinanet import OP_CONV, OP_MAXPOOL, OP_RELU, OP_STEM, OP_TAIL, OP_TAIL_NEXT
@@ -361,7 +363,7 @@ def check_every_layer(backbone, dtype, fuse_next, batch, h, w, monkeypatch):
     planes = synthetic.load_plane_database('10').astype(np.float32)
     _, P_inv = synthetic.synthetic_calibration()
     plan = model50.stage_inputs([img, np.tile(P_inv[None], (batch, 1, 1)), planes])
-    ref = net_torch.forward(weights, img, backbone, storage=None if dtype == 'f32' else dtype, trace=True)
+    ref = net_torch.forward(weights, img, backbone, storage=None if dtype in ('f32', 'bf16x3') else dtype, trace=True)
     tr = ref['trace']
     ulp = 1.0 / 128 if dtype == 'bf16' else 1.0 / 1024
 
@@ -395,7 +397,8 @@ def check_every_layer(backbone, dtype, fuse_next, batch, h, w, monkeypatch):
         rms = float(np.sqrt((want.astype(np.float64) ** 2).mean())) + 1e-30
         err = np.abs(got - want)
         if fm.buf.dtype == torch.float32:
-            assert (err <= 2e-5 * rms + 1e-5 * np.abs(want)).all(), (name, err.max(), rms)
+            k = 10.0 if dtype == 'bf16x3' else 1.0
+            assert (err <= k * (2e-5 * rms + 1e-5 * np.abs(want))).all(), (name, err.max(), rms)
         else:
             assert (err <= np.abs(want) * ulp + slack * rms).all(), (name, err.max(), rms)
             assert (got == want).mean() >= 0.99, (name, (got == want).mean())

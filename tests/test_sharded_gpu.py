@@ -32,7 +32,9 @@ def test_two_process_shards_equal_the_single_process_batch(dtype, tmp_path):
     batch, h, w = 4, 402, 1333
     out_path = str(tmp_path / 'gathered.npy')
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    debug_dir = os.path.join(ROOT, 'gpurun_out', 'sharded_debug_{}'.format(dtype))
+    os.makedirs(debug_dir, exist_ok=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GPP_SHARD_DEBUG_DIR=debug_dir)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'sharded_worker.py'), str(r), '2', str(port), str(batch),
                                str(h), str(w), dtype, out_path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               universal_newlines=True) for r in range(2)]
@@ -58,7 +60,9 @@ def test_two_process_shards_equal_the_single_process_batch(dtype, tmp_path):
         os.makedirs(os.path.dirname(dump), exist_ok=True)
         outs2 = model.predict_on_batch(list(sharded_worker.global_inputs(batch, h, w)))       # which side moved?
         second = np.concatenate([np.asarray(o, np.float32).reshape(batch, 100, -1) for o in outs2], axis=2)
-        np.savez(dump, gathered=gathered, single=single, second=second)
+        plan = model.plan_for(batch, h, w, 1000, True)
+        np.savez(dump, gathered=gathered, single=single, second=second, planes=plan.planes.cpu().numpy(),
+                 canon=plan.poll_ws.cpu().numpy().view(np.float32), P_inv=plan.P_inv.cpu().numpy(), best=plan.best_index.cpu().numpy())
         raise AssertionError('gathered != single: {} (image, detection) rows differ, first {}, columns {}, max |diff| {}; a second '
                              'single-process run equals the first: {}, equals the gathered result: {}; arrays in {}'.format(
                                  len(rows), rows[:5].tolist(), sorted(set(np.argwhere(d > 0)[:, 2].tolist())), d.max(),
