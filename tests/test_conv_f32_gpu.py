@@ -143,11 +143,12 @@ def test_every_bf16x3_tile_gives_identical_results(case):
             continue
         C.run_conv(d)
         assert torch.equal(out.buf, base), tile
-    out.buf.fill_(float('nan'))
-    C.run_conv(make(96128, split_k=3, workspace=True))
-    first = out.buf.clone()
-    C.run_conv(make(192128, split_k=3, workspace=True))               # split-K: same summation order on every tile
-    assert torch.equal(out.buf, first)
+    if case in ('3x3_wide', 'deepK'):                                   # enough K-steps to split
+        out.buf.fill_(float('nan'))
+        C.run_conv(make(96128, split_k=3, workspace=True))
+        first = out.buf.clone()
+        C.run_conv(make(192128, split_k=3, workspace=True))           # split-K: same summation order on every tile
+        assert torch.equal(out.buf, first)
 
 
 def test_pipelined_and_wide_tiles_are_16_bit_only():
