@@ -148,6 +148,7 @@ class RetinaNet3D(object):
     # ------------------------------------------------------------------ weights
     def _upload(self, weights):
         torch, dev = self.torch, self.device
+        W.validate_weights(weights, self.backbone_name)
         self.conv_w = {}
 
         def put(name, kernel, bias):

@@ -133,8 +133,36 @@ def synthetic_weights(backbone='resnet50', seed=1234):
     return w
 
 
+def expected_arrays(backbone):
+    """ {array name: shape} of every array the graph of `backbone` + FPN + heads needs (Keras names and layouts) """
+    exp = {}
+    for conv, bn, kh, kw, cin, cout, _ in backbone_layers(backbone):
+        exp[conv + '/kernel'] = (kh, kw, cin, cout)
+        for part in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+            exp['{}/{}'.format(bn, part)] = (cout,)
+    for name, k, cin, cout, _ in fpn_layers():
+        exp[name + '/kernel'], exp[name + '/bias'] = (k, k, cin, cout), (cout,)
+    for name, cin, cout, _ in head_layers():
+        exp[name + '/kernel'], exp[name + '/bias'] = (3, 3, cin, cout), (cout,)
+    return exp
+
+
+def validate_weights(weights, backbone):
+    """ Every expected array present with the expected shape, else ONE ValueError that names what is wrong (a converted
+    checkpoint with a missing or transposed layer otherwise surfaces as a KeyError deep inside the plan builder). """
+    exp = expected_arrays(backbone)
+    missing = sorted(k for k in exp if k not in weights)
+    wrong = sorted('{}: {} (expected {})'.format(k, tuple(np.shape(weights[k])), exp[k])
+                   for k in exp if k in weights and tuple(np.shape(weights[k])) != exp[k])
+    if missing or wrong:
+        raise ValueError('weights do not match {} + FPN + heads: {} arrays missing{}{}; {} with a wrong shape{}{}'.format(
+            backbone, len(missing), ': ' if missing else '', ', '.join(missing[:8]) + (' ...' if len(missing) > 8 else ''),
+            len(wrong), ': ' if wrong else '', '; '.join(wrong[:8]) + (' ...' if len(wrong) > 8 else '')))
+
+
 def load_weights(path):
-    """ '.npz' written by save_weights, or a Keras '.h5' (needs h5py, absent from this image). """
+    """ '.npz' written by save_weights, or a Keras '.h5' (needs h5py, absent from this image: that branch has never run
+    here -- DESIGN.md section 2 row f2 says "npz only"). """
     if path.endswith('.npz'):
         with np.load(path) as z:
             return {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
@@ -151,7 +179,10 @@ def load_weights(path):
             def visit(name, obj):
                 if isinstance(obj, h5py.Dataset):
                     parts = name.split('/')
-                    out['{}/{}'.format(parts[-2], parts[-1].split(':')[0])] = np.asarray(obj, dtype=np.float32)
+                    key = '{}/{}'.format(parts[-2], parts[-1].split(':')[0])
+                    if key in out:          # nested sub-models must not overwrite each other silently
+                        raise ValueError('{}: array {} appears twice (second time at {})'.format(path, key, name))
+                    out[key] = np.asarray(obj, dtype=np.float32)
 
             root.visititems(visit)
         return out

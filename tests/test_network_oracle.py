@@ -70,3 +70,23 @@ def test_weight_file_round_trip(tmp_path):
     back = W.load_weights(str(tmp_path / 'w.npz'))
     assert set(back) == set(small) and all(np.array_equal(back[k], small[k]) for k in small)
     assert np.array_equal(W.synthetic_weights('resnet50', 5)['P7/kernel'], w['P7/kernel'])     # seeded, reproducible
+
+
+def test_weight_validation_names_missing_and_misshaped_arrays():
+    """ models.weights.validate_weights: one clear error instead of a KeyError deep in the plan builder (a converted
+    checkpoint with a missing / transposed layer); synthetic weights of every backbone validate """
+    import pytest
+    from keras_retinanet_3D.models import weights as W
+    for backbone in ('resnet50', 'resnet101', 'resnet152'):
+        exp = W.expected_arrays(backbone)
+        assert 'res5c_branch2c/kernel' in exp and exp['pyramid_regression_op1/kernel'] == (3, 3, 512, 48)
+    w = W.synthetic_weights('resnet50', 3)
+    W.validate_weights(w, 'resnet50')
+    broken = dict(w)
+    del broken['P4/kernel']
+    broken['res3b_branch2b/kernel'] = np.transpose(broken['res3b_branch2b/kernel'], (3, 2, 0, 1))      # OIHW instead of HWIO
+    with pytest.raises(ValueError) as e:
+        W.validate_weights(broken, 'resnet50')
+    assert 'P4/kernel' in str(e.value) and 'res3b_branch2b/kernel' in str(e.value) and '1 arrays missing' in str(e.value)
+    with pytest.raises(ValueError):
+        W.validate_weights(w, 'resnet101')              # resnet50 weights are not a resnet101
