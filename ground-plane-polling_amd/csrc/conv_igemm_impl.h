@@ -1275,8 +1275,16 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                     default: return GPP_ERR_BAD_ARG;
                 }
             } else {
+                // GPP_BF16X3 spends 3 MFMAs per fragment pair: with 4-wavefront tiles its LDS traffic equals its matrix time;
+                // the 8-wavefront 256-column tiles (plain two-buffer loop) halve the LDS bytes per MFMA
+                if constexpr (DT == GPP_BF16X3) {
+                    if (d.tile_hint == 256256) return launch<DT, 256, 256, 2, 4, 2, false>(d, st);
+                    if (d.tile_hint == 192256) return launch<DT, 192, 256, 2, 4, 2, false>(d, st);
+                    if (d.tile_hint == 128256) return launch<DT, 128, 256, 2, 4, 2, false>(d, st);
+                }
                 switch (d.tile_hint) {
                     case 256: case 1128128: case 1192128: case 1128256: case 1192256: case 1192160: case 2256256: case 512: case 256256:
+                    case 192256: case 128256:
                         return GPP_ERR_UNSUPPORTED;
                     default: return GPP_ERR_BAD_ARG;
                 }

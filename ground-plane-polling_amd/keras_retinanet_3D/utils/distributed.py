@@ -11,7 +11,7 @@ image (RCCL over xGMI under torch.distributed backend 'nccl'; latency-bound at t
 No reduction takes place, and every bit of an image's result is a function of (image, weights, dtype) alone -- block tiles
 are tuned per process but never change a result, split-K follows a rule of the layer alone (include/gpp.h,
 gpp_conv2d_split_rule) -- so the gathered result is bit-identical to a single-GPU run of the whole batch
-(tests/test_sharded_gpu.py: two processes with the real model against one process, byte for byte).
+(tests/test_zz_sharded_gpu.py: two processes with the real model against one process, byte for byte).
 """
 
 import numpy as np

@@ -1,5 +1,5 @@
 """
-Child process of tests/test_sharded_gpu.py: one rank of an image-sharded run of the REAL model.
+Child process of tests/test_zz_sharded_gpu.py: one rank of an image-sharded run of the REAL model.
     python sharded_worker.py <rank> <world> <port> <global_batch> <H> <W> <dtype> <out.npy>
 Every rank builds its own model (its own block-tile tuning run), takes its contiguous shard of the seeded global batch,
 and the ranks exchange the packed detections over a gloo group (both ranks share the one GPU of the test box; the

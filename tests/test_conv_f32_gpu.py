@@ -22,6 +22,7 @@ from test_conv_gpu import CASES, tf_nearest
 pytestmark = pytest.mark.gpu
 
 F32_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128, 128160, 192160]
+X3_TILES = F32_TILES + [128256, 192256, 256256]          # GPP_BF16X3 also has the 8-wavefront 256-column tiles (plain loop)
 
 
 def reference64(x, k, bias, stride, pad_t, pad_l, oh, ow, relu, res):
@@ -136,7 +137,7 @@ def test_every_bf16x3_tile_gives_identical_results(case):
     make, out, _, _, _ = _layer([c for c in CASES if c[0] == case][0], dtype='bf16x3')
     C.run_conv(make(128128))
     base = out.buf.clone()
-    for tile in F32_TILES:
+    for tile in X3_TILES:
         out.buf.fill_(float('nan'))
         d = make(tile)
         if -(-d.C_out // (tile % 1000)) * (tile % 1000) > d.weight_rows:

@@ -38,7 +38,8 @@ def short(k):
     return k[:40]
 
 
-def main(path, backbone='resnet50'):
+def main(path, backbone='resnet50', fused='0,1'):
+    """ fused: stages whose 2b+2c run as one launch ('0,1' = the 16-bit default; '' for the float32-storage types) """
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     ours = [r for r in rows if 'at::native' not in r['Kernel_Name'] and 'rocclr' not in r['Kernel_Name']]
@@ -48,7 +49,7 @@ def main(path, backbone='resnet50'):
     # take the middle of the first 13 (warmup 3 + 10 timed with the profiling command of profiles/README.md)
     steps = [ours[a:b] for a, b in zip(starts, starts[1:] + [len(ours)]) if any('poll_kernel' in r['Kernel_Name'] for r in ours[a:b])]
     step = steps[min(8, len(steps) - 1)]
-    names = conv_names(backbone)
+    names = conv_names(backbone, tuple(int(v) for v in fused.split(',') if v.strip()))
     ci = 0
     t0 = int(step[0]['Start_Timestamp'])
     total = 0.0
