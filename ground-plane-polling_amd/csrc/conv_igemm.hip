@@ -184,7 +184,8 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                                  1128128, 1192128, 1128256, 1192256, 256256,
                                  128160, 192160, 1192160, 2256256,
-                                 128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
+                                 128256, 192256,             // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
+                                 3064128, 3096128, 3128128, 3064256};   // 16-bit only: loader-wavefront form (conv_ring_impl.h)
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);
@@ -218,12 +219,14 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     };
     for (int tile : kTiles) {
         const int bn = tile % 1000 ? tile % 1000 : 128;
+        if (tile >= 3000000 && f32_storage(desc->dtype)) continue;
         if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
         if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) continue;
-        if (tile > 1000000 && (nk < 4 || f32_storage(desc->dtype))) continue;   // the pipelined loop needs a few K-steps to pay; 16-bit only
+        if (tile > 1000000 && tile < 3000000 && (nk < 4 || f32_storage(desc->dtype))) continue;   // the pipelined loop needs a few K-steps to pay; 16-bit only
         if (bn == 256 && desc->dtype == GPP_F32) continue;
         if ((tile == 128256 || tile == 192256) && desc->dtype != GPP_BF16X3) continue;
         if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding
+        if (tile >= 3000000 && bn == 256 && desc->C_out < 192) continue;
         if (tile == 2256256 && (desc->C_out < 384 || desc->C_out % 256 != 128 || rows < 256 * 16)) continue;   // dual-shape grid: C_out = 256 k + 128
         float us = 0.0f;
         int r = time_one(tile, &us);

@@ -96,7 +96,7 @@ def test_conv_matches_torch_fp32(case, dtype, tile):
     assert abs(C.conv_flops(d) - 2.0 * B * oh * ow * K * K * Cin * Cout) < 1.0
 
 
-@pytest.mark.parametrize('tile', [128, 256])
+@pytest.mark.parametrize('tile', [128, 256, 3064128, 3128128])
 def test_grouped_pyramid_launch_and_channel_slices(tile):
     """ five feature maps of different sizes in one launch, inputs read as a channel slice of a
     wider tensor, outputs written at level offsets of one (B, sum(HW), C) pyramid tensor """
@@ -175,7 +175,8 @@ def test_split_k_matches_torch_fp32(case, split):
 
 ALL_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
              1128128, 1192128, 1128256, 1192256, 256256,
-             128160, 192160, 1192160]                 # N-remainder tiles (4 x 1 wavefronts, 160 columns)
+             128160, 192160, 1192160,                 # N-remainder tiles (4 x 1 wavefronts, 160 columns)
+             3064128, 3096128, 3128128, 3064256]      # loader-wavefront form (csrc/conv_ring_impl.h): 5 wavefronts, activation ring
 
 
 def _layer(name, dtype='bf16', workspace=False):
@@ -230,6 +231,28 @@ def test_every_tile_gives_identical_results(case):
             continue
         C.run_conv(d)
         assert torch.equal(out.buf.float().cpu(), base), tile
+
+
+@pytest.mark.parametrize('tile', [3064128, 3096128, 3128128, 3064256])
+@pytest.mark.parametrize('case', ['deepK', '3x3_wide', 'bottleneck_2c', '1x1_s2', '1x1'])
+def test_loader_wavefront_form_with_split_k_and_both_types(case, tile):
+    """ conv_ring_kernel: same bits as the plain tile with and without split-K (K-step counts 1 .. 144 around its ring depth
+    and its register sets), bf16 and f16 """
+    for dtype in ('bf16', 'f16'):
+        make, out, ref, eps = _layer(case, dtype=dtype, workspace=True)
+        if -(-make(0).C_out // (tile % 1000)) * (tile % 1000) > make(0).weight_rows:
+            continue
+        for split in (1, 2, 3):
+            nk = make(0).KH * make(0).KW * (make(0).C_in // 64)
+            if nk < split:
+                continue
+            out.buf.fill_(float('nan'))
+            C.run_conv(make(128128, split_k=split))
+            base = out.buf.float().cpu()
+            assert bool(((base - ref).abs() <= eps * ref.abs() + 1e-3).all())
+            out.buf.fill_(float('nan'))
+            C.run_conv(make(tile, split_k=split))
+            assert torch.equal(out.buf.float().cpu(), base), (dtype, split)
 
 
 def test_unknown_tile_code_is_rejected():
