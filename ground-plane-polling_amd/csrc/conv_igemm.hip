@@ -184,8 +184,9 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                                  1128128, 1192128, 1128256, 1192256, 256256,
                                  128160, 192160, 1192160, 2256256,
-                                 128256, 192256,             // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
-                                 3064128, 3096128, 3128128, 3064256};   // 16-bit only: loader-wavefront form (conv_ring_impl.h)
+                                 128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
+    // (the loader-wavefront form, tile codes 3064128 / 3096128 / 3128128 / 3064256 of conv_ring_impl.h, is not a candidate:
+    // measured 1.5 - 2x slower than the plain tiles on every latency-bound layer it was built for, profiles/r2/ring_kernel.txt)
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);

@@ -22,6 +22,14 @@
 // LDS holds only activations: 64-row tile x 6 slots = 48 KB -> 3 workgroups per CU with 5 activation K-steps in flight
 // each (120 KB per CU against 24 KB in the two-buffer loop).
 //
+// MEASURED AND REJECTED (MI355X, B = 8, tools/bench_conv.py ring, profiles/r2/ring_kernel.txt): 1.5 - 2x SLOWER than the plain
+// two-buffer tiles on every layer it was built for (res4 2a: 36 - 40 us against 20 - 21 us; res5 2b: 59 - 83 against 45; P4: 169 -
+// 211 against 84), hot and cold alike.  The premise was wrong: those layers are not waiting for latency, they are bound by the
+// CU's vector-memory instruction throughput -- a 1 KB wave-instruction (LDS-DMA piece or global_load_dwordx4 alike) retires
+// every 20 - 30 ns per CU, i.e. 35 - 50 GB/s per CU whatever the destination, and this form issues the same number of them (the
+// register-direct weight fragments touch twice as many cache lines on top).  Kept, tested and reachable by explicit tile code
+// as the record of that experiment; the autotuner does not consider it.
+//
 // The K order of every output element is the one of conv_igemm_kernel (channel chunk, kh, kw; kk = 0, 1 inside a K-step), and
 // the epilogue is the same arithmetic: results are bit-identical to every other block tile (tests/test_conv_gpu.py).
 #ifndef GPP_CONV_RING_IMPL_H_

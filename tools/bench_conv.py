@@ -378,3 +378,42 @@ if __name__ == '__main__':
     bench('res5 3x3 512->512', B, [(13, 42)], 512, 512, 3)
     bench('res5 1x1 512->2048', B, [(13, 42)], 512, 2048, 1)
     bench('f16 reg tower 3x3', B, PYR, 512, 512, 3, dtype='f16')
+    if len(sys.argv) > 2 and sys.argv[2] == 'ring':
+        # loader-wavefront form (conv_ring_kernel) against the plain tiles on the latency-bound layers.  Back to back on the
+        # same buffers (inputs Infinity-Cache resident) AND with a 600 MB buffer rewritten between launches ("cold": inputs
+        # come from HBM, closer to the network where another layer's output is what was written last)
+        flush = torch.empty((600 << 20,), dtype=torch.uint8, device='cuda')
+
+        def cold(name, shapes, cin, cout, k, tile, residual=False):
+            dev = torch.device('cuda')
+            total = sum(h * w for h, w in shapes)
+            x = (torch.randn((B, total, cin), device=dev) * 0.5).to(torch.bfloat16)
+            o = torch.empty((B, total, cout), device=dev, dtype=torch.bfloat16)
+            w = C.pack_weight((torch.randn((k, k, cin, cout)) * 0.02).numpy(), 'bf16', dev)
+            bias = torch.zeros((cout,), device=dev)
+            ins = [C.FMap(x, B, shapes[0][0], shapes[0][1], cin)]
+            outs = [C.FMap(o, B, shapes[0][0], shapes[0][1], cout)]
+            res = [C.FMap((torch.randn((B, total, cout), device=dev) * 0.5).to(torch.bfloat16), B, shapes[0][0], shapes[0][1], cout)] if residual else None
+            d = C.conv_desc(ins, outs, w, bias, k, k, cin, cout, pad=(k // 2, k // 2), relu=True, tile_hint=tile, residuals=res)
+            C.run_conv(d)
+            ts = []
+            for _ in range(6):
+                flush.fill_(1)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                C.run_conv(d)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            return sorted(ts)[len(ts) // 2]
+
+        for name, shp, cin, cout, k, res in (('res4 2a 1x1 1024->256', [(26, 84)], 1024, 256, 1, False), ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3, False),
+                                              ('res4 2c 1x1 256->1024 +res', [(26, 84)], 256, 1024, 1, True), ('res5 2a 1x1 2048->512', [(13, 42)], 2048, 512, 1, False),
+                                              ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3, False), ('res5 2c 1x1 512->2048 +res', [(13, 42)], 512, 2048, 1, True),
+                                              ('P4 3x3 512->512', [(26, 84)], 512, 512, 3, False), ('C3_reduced 1x1 512->512', [(51, 167)], 512, 512, 1, False),
+                                              ('res3 2a 1x1 512->128', [(51, 167)], 512, 128, 1, False)):
+            for tile in (64128, 96128, 128128, 160128, 3064128, 3096128, 3128128, 3064256):
+                if tile == 3064256 and cout < 256:
+                    continue
+                hot = bench('%s tile %d' % (name, tile), B, shp, cin, cout, k, tile=tile, residual=res, iters=20)
+                print('    cold (inputs from HBM): %.1f us   hot %.1f us' % (cold(name, shp, cin, cout, k, tile, res), hot * 1e3))
