@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include <float.h>
 #include <limits.h>
+#include <stdlib.h>
 
 #include "gpp.h"
 
@@ -87,6 +88,10 @@ __global__ void canonical_planes_kernel(const float4* __restrict__ planes, float
     canon[j] = make_float4(a / nn, b / nn, c / nn, d / nn);
 }
 
+// UNROLL planes of a lane are evaluated per loop iteration (independent instruction streams: the exact divide / square-root
+// sequences are long dependent chains, and a detection's workgroup brings only four wavefronts to its CU); the selection
+// state is updated in ascending plane order afterwards, so the result is the same for every UNROLL.
+template <int UNROLL>
 __global__ __launch_bounds__(kThreads) void poll_kernel(
     const float* __restrict__ boxes, const float* __restrict__ dims, const int32_t* __restrict__ orient,
     const float* __restrict__ P_inv, const float4* __restrict__ canon, int D, int N, int planes_batched, float thr,
@@ -128,8 +133,7 @@ __global__ __launch_bounds__(kThreads) void poll_kernel(
     float rmin = INFINITY;     // best residual among level-`level` planes with zc >= 0
     int imin = INT_MAX;
     int i100 = INT_MAX;        // lowest index that carries the sentinel if `level` is the maximum
-    for (int j = tid; j < N; j += kThreads) {
-        Hyp hy = evaluate(ray, pl[j], target, thr);
+    auto update = [&](const Hyp& hy, int j) {
         int v = (int)hy.votes;
         if (v > level) {
             if (j != tid) i100 = tid;      // all earlier planes of this lane drop to the sentinel
@@ -141,6 +145,17 @@ __global__ __launch_bounds__(kThreads) void poll_kernel(
             float key = (hy.res < FLT_MAX) ? hy.res : INFINITY;   // NaN / inf never win
             if (key < rmin) { rmin = key; imin = j; }
         }
+    };
+    for (int j = tid; j < N; j += UNROLL * kThreads) {
+        Hyp hy[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int ju = j + u * kThreads;
+            hy[u] = evaluate(ray, pl[ju < N ? ju : j], target, thr);     // past the end: plane j again, not used
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            if (j + u * kThreads < N) update(hy[u], j + u * kThreads);
     }
 
     // ---- merge: agree on the maximum level, demote lanes below it
@@ -226,9 +241,20 @@ extern "C" int gpp_poll_f32(const float* boxes, const float* dims, const int32_t
     int64_t total = (int64_t)N * (planes_batched ? B : 1);
     canonical_planes_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(
         (const float4*)planes, (float4*)workspace, total);
-    poll_kernel<<<dim3((unsigned)(B * D)), dim3(kThreads), 0, st>>>(
-        boxes, dims, orient, P_inv, (const float4*)workspace, D, N, planes_batched, thr,
-        keypoints, keyplanes, residuals, best_idx);
+    static const int unroll = [] { const char* e = getenv("GPP_POLL_UNROLL"); return e ? atoi(e) : 0; }();      // 0 = by N (tools/bench_poll.py)
+    // measured (MI355X, 8 x 100 detections): 10k planes 94.5 / 91.0 / 90.4 us with 1 / 2 / 4 planes per iteration, 22k planes
+    // (4 x 100) 113 / 109 / 104 us, 1k planes no difference: the kernel is bound by VALU issue (about 300 instructions per pair
+    // for the exact IEEE divides and square roots), not by latency
+    const int u = unroll ? unroll : (N >= 16 * kThreads ? 4 : (N >= 4 * kThreads ? 2 : 1));
+    if (u >= 4)
+        poll_kernel<4><<<dim3((unsigned)(B * D)), dim3(kThreads), 0, st>>>(boxes, dims, orient, P_inv, (const float4*)workspace, D, N,
+                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx);
+    else if (u >= 2)
+        poll_kernel<2><<<dim3((unsigned)(B * D)), dim3(kThreads), 0, st>>>(boxes, dims, orient, P_inv, (const float4*)workspace, D, N,
+                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx);
+    else
+        poll_kernel<1><<<dim3((unsigned)(B * D)), dim3(kThreads), 0, st>>>(boxes, dims, orient, P_inv, (const float4*)workspace, D, N,
+                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }
