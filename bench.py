@@ -352,11 +352,12 @@ def main():
         pipe = FramePipeline(model)
         list(pipe.run(iter([(frames, P_host, planes_host)] * 4)))
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_it = 30 if args.dtype != 'f32' else 4
+        n_it = 40 if args.dtype not in ('f32', 'bf16x3') else 8
+        stamps = []
         for _ in pipe.run(iter([(frames, P_host, planes_host)] * n_it)):
-            pass
-        pcie_pipelined = round(B * n_it / (time.perf_counter() - t1), 1)
+            stamps.append(time.perf_counter())
+        skip = 3                                     # steady state: results per second between the 4th and the last batch
+        pcie_pipelined = round(B * (n_it - 1 - skip) / (stamps[-1] - stamps[skip]), 1)
 
     if rank == 0:
         total_images = world * B * args.steps
