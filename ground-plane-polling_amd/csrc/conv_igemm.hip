@@ -184,8 +184,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                                  1128128, 1192128, 1128256, 1192256, 256256,
                                  128160, 192160, 1192160, 2256256,
-                                 128256, 192256,             // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
-                                 4064128, 4096128, 4128128, 4160128, 4192128};   // 16-bit, 3x3 / stride 1: patch shared by the three kernel columns
+                                 128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
     // (the loader-wavefront form, tile codes 3064128 / 3096128 / 3128128 / 3064256 of conv_ring_impl.h, is not a candidate:
     // measured 1.5 - 2x slower than the plain tiles on every latency-bound layer it was built for, profiles/r2/ring_kernel.txt)
     hipStream_t st = (hipStream_t)stream;
@@ -222,7 +221,6 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     for (int tile : kTiles) {
         const int bn = tile % 1000 ? tile % 1000 : 128;
         if (tile >= 3000000 && f32_storage(desc->dtype)) continue;
-        if (tile >= 4000000 && (desc->KH != 3 || desc->KW != 3 || desc->stride != 1 || desc->residual)) continue;
         if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
         if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) continue;
         if (tile > 1000000 && tile < 3000000 && (nk < 4 || f32_storage(desc->dtype))) continue;   // the pipelined loop needs a few K-steps to pay; 16-bit only

@@ -1,12 +1,10 @@
 // Instantiates the implicit-GEMM convolution kernels (conv_igemm_impl.h) for one element type: GPP_F16.
 #include "conv_igemm_impl.h"
 #include "conv_ring_impl.h"
-#include "conv_kw_impl.h"
 #include "conv_igemm_types.h"
 
 int gpp_conv_dispatch_f16(gpp_conv_desc& d, hipStream_t st)
 {
-    if (d.tile_hint >= 4000000) return dispatch_kw<GPP_F16>(d, st);        // 3x3: activation patch shared by the three kernel columns (conv_kw_impl.h)
     if (d.tile_hint >= 3000000) return dispatch_ring<GPP_F16>(d, st);      // loader-wavefront form (conv_ring_impl.h)
     return dispatch<GPP_F16>(d, st);
 }

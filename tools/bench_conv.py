@@ -417,11 +417,3 @@ if __name__ == '__main__':
                     continue
                 hot = bench('%s tile %d' % (name, tile), B, shp, cin, cout, k, tile=tile, residual=res, iters=20)
                 print('    cold (inputs from HBM): %.1f us   hot %.1f us' % (cold(name, shp, cin, cout, k, tile, res), hot * 1e3))
-    if len(sys.argv) > 2 and sys.argv[2] == 'kw':
-        # shared-patch 3x3 form (conv3x3_kw_kernel, tile codes 4000000 + ...) against the plain tiles
-        for name, shp, cin, cout in (('res4 2b 3x3 256->256', [(26, 84)], 256, 256), ('res5 2b 3x3 512->512', [(13, 42)], 512, 512),
-                                     ('P4 3x3 512->512', [(26, 84)], 512, 512), ('P5 3x3 512->512', [(13, 42)], 512, 512),
-                                     ('res3 2b 3x3 128->128', [(51, 167)], 128, 128), ('P3 3x3 512->512', [(51, 167)], 512, 512),
-                                     ('cls tower 3x3 256->256', PYR, 256, 256), ('dim tower 3x3 128->128', PYR, 128, 128)):
-            for tile in (64128, 96128, 128128, 160128, 192128, 4064128, 4096128, 4128128, 4160128, 4192128):
-                bench('%s tile %d' % (name, tile), B, shp, cin, cout, 3, tile=tile, iters=20)
