@@ -20,6 +20,8 @@
 #include <stdint.h>
 #include <limits.h>
 
+#include <atomic>
+
 #include "gpp.h"
 
 namespace {
@@ -670,11 +672,15 @@ int detect_impl(int stages, int lists_per_image, const float* cls_logits, const 
         else candidates_kernel<<<grid, 256, 0, st>>>(cls_logits, n_anchors, kstride, score_thr, keys, cnt);
     }
     if (stages & GPP_DETECT_SELECT) {                      // needs the candidates and the corner regressions
-        static bool configured = false;
-        if (!configured) {
+        // the dynamic-LDS attribute is per device: one bit per device ordinal (racing first calls set the same value)
+        static std::atomic<uint64_t> configured{0};
+        int dev = 0;
+        e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (!(configured.load(std::memory_order_acquire) & (1ull << (dev & 63)))) {
             e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsKeys * 16 + kHistBins * 4);
             if (e != hipSuccess) return (int)e;
-            configured = true;
+            configured.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
         nms_kernel<<<dim3((unsigned)lists), kNmsThreads, kLdsKeys * 16 + kHistBins * 4, st>>>(
             keys, cnt, kstride, cls_logits, regression, regression_dim, (const float4*)anchors, n_anchors, L, iou_thr, max_det,
