@@ -571,23 +571,24 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         asm volatile("" ::: "memory");
         GPP_KSTAMP(2);
 #ifdef GPP_STAMPS
-        if (DT != GPP_BF16X3 && issued < nk) {
+        if (issued < nk) {
             if (d.reserved & 1) { ++issued; } else issue_next();      // bit 0 (diagnostic build only): skip the LDS-DMA
         }
         GPP_KSTAMP(3);
         if (!(d.reserved & 2))                                         // bit 1 (diagnostic build only): skip LDS reads + MFMA
 #else
-        if constexpr (DT != GPP_BF16X3) { if (issued < nk) issue_next(); }
+        if (issued < nk) issue_next();
 #endif
         {
             if constexpr (DT == GPP_BF16X3) {
-                // one 32-channel K-step = one k-slice of v_mfma_f32_16x16x32_bf16, three matrix products per accumulator (the two
-                // cross terms, then the dominant hi * hi term: the same order for every tile).  The LDS-DMA pieces of the NEXT
-                // stage are issued between the row tiles' MFMA groups, not in front of them: a piece costs the issuing
-                // wavefront ~100+ cycles, and with the workgroup in lock-step behind the barrier nothing else would feed
-                // the matrix pipe meanwhile.
+                // one 32-channel K-step = one k-slice of v_mfma_f32_16x16x32_bf16, three matrix products per accumulator:
+                // the two cross terms first, the dominant hi * hi term last
                 const unsigned char* sbase = smem + cbuf * STAGE;
                 bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+                    Elem<GPP_BF16X3>::split(*(const f32x4*)(sbase + a_rdx[0] + i * 16 * kRowBytes),
+                                            *(const f32x4*)(sbase + a_rdx[1] + i * 16 * kRowBytes), ah[i], al[i]);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     bh[j] = *(const bf16x8*)(sbase + b_rd[0] + j * 16 * kRowBytes);
@@ -595,39 +596,15 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 }
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
-                    Elem<GPP_BF16X3>::split(*(const f32x4*)(sbase + a_rdx[0] + i * 16 * kRowBytes),
-                                            *(const f32x4*)(sbase + a_rdx[1] + i * 16 * kRowBytes), ah[i], al[i]);
-                const bool live = issued < nk;
-                unsigned char* sa = smem + ibuf * STAGE + wave * A_IT * 8 * kRowBytes;
-                unsigned char* sb = smem + ibuf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
-                const int so_a = cc * kRowBytes, so_w = (ks0 + issued) * kRowBytes;
 #pragma unroll
-                for (int i = 0; i < MF; ++i) {
-                    if (live) {
-#pragma unroll
-                        for (int idx = 0; idx < PER_STAGE; ++idx) {
-                            if (idx * MF / PER_STAGE != i) continue;          // piece idx goes out in front of row tile idx * MF / PER_STAGE
-                            if (idx < A_IT) glds16(in_rsrc, a_voff[idx < A_IT ? idx : 0], so_a, sa + idx * 8 * kRowBytes);
-                            else glds16(w_rsrc, w_voff[idx >= A_IT ? idx - A_IT : 0], so_w, sb + (idx - A_IT) * 8 * kRowBytes);
-                        }
+                    for (int j = 0; j < NF; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
                     }
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MF; ++i)
 #pragma unroll
                     for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (live) {                                    // the tap offsets change only after this stage's pieces are out
-                    if (++kw == d.KW) {
-                        kw = 0;
-                        if (++kh == d.KH) { kh = 0; ++cc; }
-                    }
-                    set_tap(kh, kw);
-                    ++issued;
-                    if (++ibuf == STAGES) ibuf = 0;
-                }
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
