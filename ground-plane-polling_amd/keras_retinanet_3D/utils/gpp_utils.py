@@ -117,6 +117,12 @@ def rotation_vector_from_matrix(R):
     """ cv2.Rodrigues(matrix)[0][:, 0] for a batch (n, 3, 3) -> (n, 3): orthonormalise by SVD
     (R <- U V^T), then axis * angle.  (OpenCV is absent here; restated from its documentation.) """
     R = np.asarray(R, dtype=np.float64).reshape(-1, 3, 3)
+    finite = np.isfinite(R).all(axis=(1, 2))
+    if not finite.all():                 # a degenerate detection (zero-length edge): NaN pose for that row, the others unaffected
+        out = np.full((R.shape[0], 3), np.nan)
+        if finite.any():
+            out[finite] = rotation_vector_from_matrix(R[finite])
+        return out
     U, _, Vt = np.linalg.svd(R)
     R = U @ Vt
     r = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1)

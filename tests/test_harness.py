@@ -121,3 +121,23 @@ def test_run_network_cli_end_to_end_with_a_fake_model(tmp_path, monkeypatch):
         assert np.allclose(mat[key], g['mat_' + key], atol=1e-4), key
     txt = (tmp_path / 'out' / 'mymodel' / 'outputs' / 'kitti' / '000001.txt').read_text()
     assert txt.count('\n') == str(g['kitti_text']).count('\n')
+
+
+def test_pose_recovery_survives_a_degenerate_detection():
+    """ a detection whose keypoints coincide (zero-length edge -> 0/0 axes) gives a NaN pose for THAT row only; the SVD of
+    the other rows must not be poisoned (run_network's per-detection loop in the reference isolates rows the same way) """
+    from keras_retinanet_3D.utils import gpp_utils
+    rng = np.random.default_rng(0)
+    n = 5
+    det = {'keypoints': rng.normal(size=(n, 12)).astype(np.float32) * 5, 'orientations': np.array([0, 1, 2, 3, 0], np.int32),
+           'dimensions': rng.uniform(1, 4, (n, 3)).astype(np.float32), 'boxes': rng.uniform(0, 100, (n, 12)).astype(np.float32),
+           'scores': np.linspace(0.9, 0.5, n).astype(np.float32)}
+    good = gpp_utils.recover_pose(det)
+    assert np.isfinite(good['angles']).all() and np.isfinite(good['locations']).all()
+    bad = {k: v.copy() for k, v in det.items()}
+    bad['keypoints'][2] = 1.0                     # X_l = X_m = X_r = X_t
+    with np.errstate(all='ignore'):
+        out = gpp_utils.recover_pose(bad)
+    assert not np.isfinite(out['angles'][2]).all()
+    keep = [0, 1, 3, 4]
+    assert np.array_equal(out['angles'][keep], good['angles'][keep]) and np.array_equal(out['locations'][keep], good['locations'][keep])

@@ -1,0 +1,63 @@
+"""
+CPU tests of utils/ledger.py (the end-to-end parity ledger bench.py and the GPU tests report): identical runs, a dropped
+detection, a changed plane index, a keypoint deviation, and the treatment of far-away / non-finite geometry.
+"""
+import numpy as np
+
+from keras_retinanet_3D.utils import ledger
+
+
+def fake_run(seed=0, batch=2, valid=80):
+    rng = np.random.default_rng(seed)
+    boxes = rng.uniform(0, 1000, (batch, 100, 12)).astype(np.float32)
+    dims = rng.uniform(1, 4, (batch, 100, 3)).astype(np.float32)
+    scores = np.sort(rng.uniform(0.1, 1, (batch, 100)).astype(np.float32), axis=1)[:, ::-1].copy()
+    scores[:, valid:] = -1
+    labels = np.zeros((batch, 100), np.int32)
+    orient = rng.integers(0, 4, (batch, 100)).astype(np.int32)
+    kp = (rng.normal(size=(batch, 100, 4, 3)) * 20).astype(np.float32)
+    kpl = rng.normal(size=(batch, 100, 1, 4)).astype(np.float32)
+    res = rng.uniform(size=(batch, 100)).astype(np.float32)
+    anchors = np.stack([rng.permutation(5000)[:100] for _ in range(batch)]).astype(np.int32)
+    anchors[:, valid:] = -1
+    planes = rng.integers(0, 1000, (batch, 100)).astype(np.int32)
+    return [boxes, dims, scores, labels, orient, kp, kpl, res], anchors, planes
+
+
+def test_identical_runs():
+    o, a, p = fake_run()
+    led = ledger.parity_ledger(o, a, p, o, a, p)
+    assert led['detections_ref'] == led['detections'] == led['common'] == 160
+    assert led['detection_set_agreement'] == 1.0 and led['images_with_identical_detection_lists'] == 2
+    assert led['orientation_agreement'] == 1.0 and led['plane_index_agreement'] == 1.0
+    assert led['max_keypoint_dev_m_within_100m'] == 0.0 and led['max_corner_rel_dev'] == 0.0 and led['max_box_diff_px'] == 0.0
+
+
+def test_each_kind_of_difference_is_counted_where_it_belongs():
+    o, a, p = fake_run()
+    o2 = [x.copy() for x in o]
+    a2, p2 = a.copy(), p.copy()
+    a2[1, 5] = 99999                       # another anchor survived NMS in image 1
+    p2[0, 7] += 1                          # another plane selected for detection 7 of image 0
+    o2[5][0, 3] += np.float32(0.01)        # keypoints of detection 3 of image 0 moved by 1 cm
+    o2[4][1, 9] = (o2[4][1, 9] + 1) % 4    # orientation class of detection 9 of image 1 changed
+    led = ledger.parity_ledger(o, a, p, o2, a2, p2)
+    assert led['common'] == 159 and abs(led['detection_set_agreement'] - 159 / 161) < 1e-6
+    assert led['images_with_identical_detection_lists'] == 1
+    assert abs(led['orientation_agreement'] - 158 / 159) < 1e-6
+    assert abs(led['plane_index_agreement'] - 157 / 159) < 1e-6          # the orientation change also leaves the "same plane" set
+    assert 0.0099 < led['max_keypoint_dev_m_within_100m'] < 0.0101
+
+
+def test_far_away_and_non_finite_geometry():
+    o, a, p = fake_run()
+    o[5][0, 0] *= 1e5                      # a grazing-ray detection: keypoints 10^6 m away
+    o2 = [x.copy() for x in o]
+    o2[5][0, 0] *= np.float32(1.0 + 1e-5)  # 10 m absolute, 1e-5 relative
+    o[5][1, 1, 0, 0] = np.nan              # the same non-finite value in both runs counts as equal
+    o2[5][1, 1, 0, 0] = np.nan
+    led = ledger.parity_ledger(o, a, p, o2, a, p)
+    assert led['max_keypoint_dev_m_within_100m'] == 0.0                  # the far detection is outside the 100 m range
+    assert 0.5e-5 < led['max_keypoint_rel_dev'] < 2e-5
+    o2[5][1, 2, 1, 1] = np.inf             # non-finite in one run only: an infinite deviation
+    assert ledger.parity_ledger(o, a, p, o2, a, p)['max_keypoint_rel_dev'] == np.inf
