@@ -46,7 +46,7 @@ def _run_shards(dtype, batch, h, w, tmp_path, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('dtype', ['bf16', 'f32', 'bf16x3'])
 def test_two_process_shards_equal_the_single_process_batch(dtype, tmp_path):
     """ A dependence of the result on the tile choices, the batch split or the rank is SYSTEMATIC: it shows on every run.  A
     mismatch is therefore re-run once (both sides) and the test fails if it shows again; a mismatch that does not reproduce
