@@ -467,7 +467,12 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         // zero-length descriptor (dropped by the range check) and the look-ahead reads hit a buffer
         // nobody uses: no branches inside the interleaved region.
         static_assert(STAGES == 2, "pipelined loop: two buffers");
-        const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, 0, 0x00020000);
+        // the zero-length descriptor of the tail is built from a SCALAR select of its record count: selecting between two
+        // whole descriptors made the compiler carry them in VGPRs and wrap every LDS-DMA of the loop in a waterfall loop
+        // (v_readfirstlane / v_cmp / s_and_saveexec / s_cbranch_execnz, four per K-step)
+        auto tail_rsrc = [](const void* base, int bytes, bool live) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, live ? bytes : 0, 0x00020000);
+        };
         auto issue_one = [&](int idx, int buf, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int so_a, int so_w) {
             unsigned char* sa = smem + buf * STAGE + wave * A_IT * 8 * kRowBytes;
             unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
@@ -492,7 +497,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         asm volatile("" ::: "memory");
         {
             const bool live = issued < nk;
-            const __amdgpu_buffer_rsrc_t ra = live ? in_rsrc : null_rsrc, rw = live ? w_rsrc : null_rsrc;
+            const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
 #pragma unroll
             for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 1, ra, rw, cc * kRowBytes, (ks0 + issued) * kRowBytes);
             if (live) advance_tap();
@@ -525,8 +530,10 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const bool live = issued < nk;
-            const __amdgpu_buffer_rsrc_t ra = live ? in_rsrc : null_rsrc, rw = live ? w_rsrc : null_rsrc;
-            const int so_a = cc * kRowBytes, so_w = (ks0 + issued) * kRowBytes;
+            const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
+            // wave-uniform by construction; said so explicitly: left to its own analysis the compiler kept the weight offset in a
+            // VGPR and wrapped four of the eight LDS-DMA of a K-step in waterfall loops (readfirstlane / cmp / saveexec / branch)
+            const int so_a = __builtin_amdgcn_readfirstlane(cc * kRowBytes), so_w = __builtin_amdgcn_readfirstlane((ks0 + issued) * kRowBytes);
             __builtin_amdgcn_sched_barrier(0);
             // ---- phase 1
 #pragma unroll
