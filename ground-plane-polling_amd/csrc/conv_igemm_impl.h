@@ -514,6 +514,13 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             const int cur = ks & 1;
             const unsigned char* scur = smem + cur * STAGE;
             const unsigned char* snxt = smem + (cur ^ 1) * STAGE;
+            // everything phase 1's LDS-DMA needs that is known already (descriptors, scalar offsets): computed HERE, in the shadow
+            // of phase 0's MFMAs, not behind the barrier where all eight wavefronts would do scalar arithmetic while the matrix
+            // pipe waits.  Wave-uniform by construction and said so explicitly (v_readfirstlane): left to its own analysis the
+            // compiler kept the weight offset in a VGPR and wrapped four of the eight LDS-DMA of a K-step in waterfall loops.
+            const bool live = issued < nk;
+            const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
+            const int so_a = __builtin_amdgcn_readfirstlane(cc * kRowBytes), so_w = __builtin_amdgcn_readfirstlane((ks0 + issued) * kRowBytes);
             __builtin_amdgcn_sched_barrier(0);
             // ---- phase 0
 #pragma unroll
@@ -529,11 +536,6 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const bool live = issued < nk;
-            const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
-            // wave-uniform by construction; said so explicitly: left to its own analysis the compiler kept the weight offset in a
-            // VGPR and wrapped four of the eight LDS-DMA of a K-step in waterfall loops (readfirstlane / cmp / saveexec / branch)
-            const int so_a = __builtin_amdgcn_readfirstlane(cc * kRowBytes), so_w = __builtin_amdgcn_readfirstlane((ks0 + issued) * kRowBytes);
             __builtin_amdgcn_sched_barrier(0);
             // ---- phase 1
 #pragma unroll
