@@ -9,7 +9,8 @@ Model loading surface of the reference, kept name for name for the inference pat
     'synthetic:<seed>'   seeded random weights of the exact architecture (no trained weights ship
                          with the reference, README.md:75)
     '<file>.npz'         weights saved by models.weights.save_weights (Keras layer names)
-    '<file>.h5'          a Keras inference/training model file (needs h5py)
+    '<file>.h5'          a Keras model (`model.save`) or weight (`model.save_weights`) file, the format the reference reads and
+                         writes (bin/convert_model.py:50-53): h5py when importable, else libhdf5 through ctypes (models/hdf5.py)
 """
 
 

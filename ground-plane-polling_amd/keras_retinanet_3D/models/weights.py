@@ -160,36 +160,119 @@ def validate_weights(weights, backbone):
             len(wrong), ': ' if wrong else '', '; '.join(wrong[:8]) + (' ...' if len(wrong) > 8 else '')))
 
 
+def _keras_group(layer):
+    """ the /model_weights group that holds `layer`'s variables in a file written by the reference: its own, or that of the
+    sub-model it lives in (models/retinanet.py:30,78,128; Keras stores e.g.
+    /model_weights/regression_submodel/pyramid_regression_0/kernel:0) """
+    if layer.startswith('pyramid_regression_dim'):
+        return 'regression_dim_submodel'
+    if layer.startswith('pyramid_regression'):
+        return 'regression_submodel'
+    if layer.startswith('pyramid_classification'):
+        return 'classification_submodel'
+    return layer
+
+
+def _array_key(dataset_path):
+    """ '<...>/<scope>/<variable>:0' -> '<scope>/<variable>' (the Keras variable name without its ':0' output index) """
+    parts = dataset_path.split('/')
+    if len(parts) < 2:
+        raise ValueError('dataset {} is not a Keras variable (<layer>/<variable>:0)'.format(dataset_path))
+    return '{}/{}'.format(parts[-2], parts[-1].split(':')[0])
+
+
+def _collect(path, named_arrays):
+    out = {}
+    for name, arr in named_arrays:
+        key = _array_key(name)
+        if key in out:          # nested sub-models must not overwrite each other silently
+            raise ValueError('{}: array {} appears twice (second time at {})'.format(path, key, name))
+        out[key] = np.asarray(arr, dtype=np.float32)
+    return out
+
+
+def load_keras_h5(path):
+    """ A Keras HDF5 model (`model.save`, what the reference's bin/convert_model.py:50-53 writes and models/__init__.py:81
+    reads) or weights-only file (`model.save_weights`) -> {'<layer>/<variable>': float32 array}.
+    Walks the file the way keras/engine/saving.py does: the `layer_names` attribute of the weight group, then each layer's
+    `weight_names`; files without those attributes are walked dataset by dataset.  h5py when importable, else libhdf5 through
+    ctypes (models/hdf5.py). """
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        found = []
+        with h5py.File(path, 'r') as f:
+            root = f['model_weights'] if 'model_weights' in f else f
+            if 'layer_names' in root.attrs:
+                for layer in root.attrs['layer_names']:
+                    layer = layer.decode() if isinstance(layer, bytes) else str(layer)
+                    g = root[layer]
+                    for wn in g.attrs['weight_names']:
+                        wn = wn.decode() if isinstance(wn, bytes) else str(wn)
+                        found.append((layer + '/' + wn, g[wn][()]))
+            else:
+                root.visititems(lambda name, obj: found.append((name, obj[()])) if isinstance(obj, h5py.Dataset) else None)
+        return _collect(path, found)
+    from . import hdf5
+    found = []
+    with hdf5.File(path) as f:
+        root = '/model_weights' if f.exists('/model_weights') else '/'
+        layers = f.attr(root, 'layer_names')
+        if layers is not None:
+            for layer in layers:
+                layer = layer.decode()
+                group = root.rstrip('/') + '/' + layer
+                names = f.attr(group, 'weight_names')
+                if names is None:
+                    raise ValueError('{}: layer group {} has no weight_names attribute'.format(path, group))
+                for wn in names:
+                    found.append((layer + '/' + wn.decode(), f.read(group + '/' + wn.decode())))
+        else:
+            found = sorted(f.datasets(root).items())
+    return _collect(path, found)
+
+
+def save_keras_h5(path, weights, backbone=None):
+    """ Writes `weights` in the layout of a Keras `model.save` file (see models/hdf5.py): /model_weights/<layer>/<scope>/<var>:0
+    with the layer_names / weight_names attributes, head layers below their sub-model groups as the reference nests them.
+    Carries the weights only (no model_config): it is what load_keras_h5 / load_model read back, and a fixture in the
+    reference's format -- not a file `keras.models.load_model` could rebuild a graph from. """
+    from . import hdf5
+    order = ('kernel', 'bias', 'gamma', 'beta', 'moving_mean', 'moving_variance')      # Keras variable order within a layer
+    groups = {}
+    for key in weights:
+        layer, var = key.rsplit('/', 1)
+        groups.setdefault(_keras_group(layer), []).append((layer, var))
+    with hdf5.File(path, 'w') as f:
+        f.create_group('/model_weights')
+        for at in ('/', '/model_weights'):
+            f.write_attr(at, 'keras_version', b'2.2.0')
+            f.write_attr(at, 'backend', b'tensorflow')
+        f.write_attr('/model_weights', 'layer_names', [g.encode() for g in groups])
+        for group, members in groups.items():
+            members.sort(key=lambda lv: (lv[0], order.index(lv[1]) if lv[1] in order else len(order)))
+            f.create_group('/model_weights/' + group)
+            f.write_attr('/model_weights/' + group, 'weight_names', ['{}/{}:0'.format(l, v).encode() for l, v in members])
+            for layer, var in members:
+                f.write_dataset('/model_weights/{}/{}/{}:0'.format(group, layer, var), weights['{}/{}'.format(layer, var)])
+
+
 def load_weights(path):
-    """ '.npz' written by save_weights, or a Keras '.h5' (needs h5py, absent from this image: that branch has never run
-    here -- DESIGN.md section 2 row f2 says "npz only"). """
+    """ '.npz' written by save_weights, or a Keras '.h5' / '.hdf5' model or weight file (load_keras_h5) """
     if path.endswith('.npz'):
         with np.load(path) as z:
             return {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
     if path.endswith('.h5') or path.endswith('.hdf5'):
-        try:
-            import h5py
-        except ImportError:
-            raise ImportError('reading a Keras .h5 model needs h5py; convert it to .npz with the layer names '
-                              'documented in keras_retinanet_3D/models/weights.py')
-        out = {}
-        with h5py.File(path, 'r') as f:
-            root = f['model_weights'] if 'model_weights' in f else f
-
-            def visit(name, obj):
-                if isinstance(obj, h5py.Dataset):
-                    parts = name.split('/')
-                    key = '{}/{}'.format(parts[-2], parts[-1].split(':')[0])
-                    if key in out:          # nested sub-models must not overwrite each other silently
-                        raise ValueError('{}: array {} appears twice (second time at {})'.format(path, key, name))
-                    out[key] = np.asarray(obj, dtype=np.float32)
-
-            root.visititems(visit)
-        return out
+        return load_keras_h5(path)
     raise ValueError('unknown weight file type: {}'.format(path))
 
 
 def save_weights(path, weights):
+    """ '.npz' (NumPy) or '.h5' / '.hdf5' (Keras layout, save_keras_h5) by extension """
+    if path.endswith('.h5') or path.endswith('.hdf5'):
+        return save_keras_h5(path, weights)
     np.savez(path, **weights)
 
 

@@ -130,6 +130,29 @@ def test_deterministic_and_shared_planes(model50):
         assert helpers.bits_equal(x, y) and helpers.bits_equal(x, z)
 
 
+def test_model_loaded_from_a_keras_h5_checkpoint(model50, tmp_path):
+    """ the reference's checkpoint format (bin/convert_model.py:50-53 -> models/__init__.py:81): a model loaded from an .h5 in
+    the Keras layout returns the bytes of the model built from the same arrays in memory """
+    from keras_retinanet_3D.models import hdf5
+    try:
+        hdf5.library()
+    except hdf5.Hdf5Error as e:
+        pytest.skip(str(e))
+    path = str(tmp_path / 'resnet50_inference.h5')
+    W.save_weights(path, W.synthetic_weights('resnet50', 1234))
+    model = models.load_model(path, backbone_name='resnet50', convert=False)
+    batch, h, w = 2, 96, 160
+    img = images(batch, h, w, seed=21)
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    P_inv = np.tile(P_inv[None].astype(np.float32), (batch, 1, 1))
+    a = model.predict_on_batch([img, P_inv, planes])
+    b = model50.predict_on_batch([img, P_inv, planes])
+    assert (a[2] > 0.05).sum() > 0
+    for x, y in zip(a, b):
+        assert helpers.bits_equal(x, y)
+
+
 def test_decode_overlap_does_not_change_results(monkeypatch):
     """ default plan: classification + regression towers first, detection selection on a side stream underneath the
     dimension tower; GPP_DECODE_OVERLAP=0: the serial order.  Same kernels, same inputs: identical outputs.
