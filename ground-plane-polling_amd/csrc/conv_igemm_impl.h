@@ -236,6 +236,43 @@ __device__ __forceinline__ RowAddr row_addr(const gpp_conv_desc& d, int m, int H
     return a;
 }
 
+// Output pixel (b, oy, ox) of GEMM row m, and the walk to row m + n without dividing again: a workgroup's setup used to
+// spend two integer divisions (~35 VALU instructions each) on every staged / prefetched / stored row -- 1.3-2.4 us of the
+// 7-17 us a small-tile workgroup lives (profiles/r2/small_layer_stamps.txt).
+struct PixWalk {
+    int b, oy, ox;
+    __device__ __forceinline__ void init(int m, int HoWo, int W_out)
+    {
+        b = m / HoWo;
+        const int p = m - b * HoWo;
+        oy = p / W_out;
+        ox = p - oy * W_out;
+    }
+    __device__ __forceinline__ void advance(int n, int H_out, int W_out)
+    {
+        ox += n;
+        while (ox >= W_out) { ox -= W_out; ++oy; }
+        while (oy >= H_out) { oy -= H_out; ++b; }
+    }
+};
+
+__device__ __forceinline__ RowAddr row_addr_at(const gpp_conv_desc& d, const PixWalk& w, int W_out, int H_out, int H_res, int W_res,
+                                               int64_t out_off, int64_t out_bs, int64_t res_off, int64_t res_bs)
+{
+    const int p = w.oy * W_out + w.ox;
+    int64_t rp = p;
+    if (d.residual && (H_res != H_out || W_res != W_out)) {
+        const float sy = (float)H_res / (float)H_out, sx = (float)W_res / (float)W_out;
+        const int ry = min((int)floorf((float)w.oy * sy), H_res - 1);
+        const int rx = min((int)floorf((float)w.ox * sx), W_res - 1);
+        rp = (int64_t)ry * W_res + rx;
+    }
+    RowAddr a;
+    a.obase = out_off + (int64_t)w.b * out_bs + (int64_t)p * d.out_pitch;
+    a.rbase = res_off + (int64_t)w.b * res_bs + rp * d.res_pitch;
+    return a;
+}
+
 // float32 storage, three bf16 MFMAs per product (GPP_BF16X3): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (x - hi is
 // exact in float32), x * w ~ hi*whi + hi*wlo + lo*whi; the dropped lo*wlo term and the two roundings of lo leave a relative
 // error of about 2^-16 per product -- 2^8 closer to float32 than plain bf16 operands, at a third of the bf16 matrix rate.
@@ -328,20 +365,23 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     // (a scalar) when both bits are set, else kOutOfRange: ~4 VALU per row and step.
     int a_base[A_IT], a_mask[A_IT], a_voff[A_IT];
     const int pitch2 = d.in_pitch * ESZ;                // bytes per input pixel
+    {
+        PixWalk pw;                                     // rows m, m + 8, m + 16, ...: one pair of divisions, then a walk
+        pw.init(m0 + wave * A_IT * 8 + srow, HoWo, W_out);
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + (wave * A_IT + i) * 8 + srow;
-        a_mask[i] = 0;
-        a_base[i] = 0;
-        if (m < Mg) {
-            const int b = m / HoWo, p = m - b * HoWo;
-            const int oy = p / W_out, ox = p - oy * W_out;
-            const int iy0 = oy * d.stride - d.pad_top, ix0 = ox * d.stride - d.pad_left;
-            int mask = 0;
-            for (int k = 0; k < d.KH; ++k) mask |= ((unsigned)(iy0 + k) < (unsigned)H_in) << k;
-            for (int k = 0; k < d.KW; ++k) mask |= ((unsigned)(ix0 + k) < (unsigned)W_in) << (8 + k);
-            a_mask[i] = mask;
-            a_base[i] = (int)((in_off + (int64_t)b * in_bs) * ESZ) + gchunk * 16 + (iy0 * W_in + ix0) * pitch2;
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + (wave * A_IT + i) * 8 + srow;
+            a_mask[i] = 0;
+            a_base[i] = 0;
+            if (m < Mg) {
+                const int iy0 = pw.oy * d.stride - d.pad_top, ix0 = pw.ox * d.stride - d.pad_left;
+                int mask = 0;
+                for (int k = 0; k < d.KH; ++k) mask |= ((unsigned)(iy0 + k) < (unsigned)H_in) << k;
+                for (int k = 0; k < d.KW; ++k) mask |= ((unsigned)(ix0 + k) < (unsigned)W_in) << (8 + k);
+                a_mask[i] = mask;
+                a_base[i] = (int)((in_off + (int64_t)pw.b * in_bs) * ESZ) + gchunk * 16 + (iy0 * W_in + ix0) * pitch2;
+            }
+            if (i + 1 < A_IT) pw.advance(8, H_out, W_out);
         }
     }
     int w_voff[B_IT];
@@ -395,10 +435,14 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     const bool use_pre = RESPRE && d.residual != nullptr && gridDim.y == 1 && (d.C_out & 7) == 0;
     if constexpr (RESPRE) {
         if (use_pre) {
+            PixWalk pw;
+            pw.init(m0 + wm * (BM / WM) + (lane & 15), HoWo, W_out);
+            const PixWalk first = {0, 0, 0};
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
-                ra_pre[i] = row_addr(d, m < Mg ? m : 0, HoWo, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
+                ra_pre[i] = row_addr_at(d, m < Mg ? pw : first, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
+                if (i + 1 < MF) pw.advance(16, H_out, W_out);
 #pragma unroll
                 for (int jj = 0; jj < NF / 2; ++jj) {
                     const int n = n0 + wn * (BN / WN) + jj * 32 + (lane >> 4) * 8;
@@ -725,11 +769,14 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         }
         return;
     }
+    PixWalk pwe;
+    pwe.init(m0 + wm * (BM / WM) + frow, HoWo, W_out);
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + frow;
-        if (m >= Mg) continue;
-        const RowAddr ra = row_addr(d, m, HoWo, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
+        if (m >= Mg) break;                                            // rows ascend with i
+        const RowAddr ra = row_addr_at(d, pwe, W_out, H_out, H_res, W_res, out_off, out_bs, res_off, res_bs);
+        pwe.advance(16, H_out, W_out);
         const scalar* rrow = res ? res + ra.rbase : nullptr;
 #pragma unroll
         for (int jj = 0; jj < NF / 2; ++jj) {
@@ -878,20 +925,23 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
     const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d2.weight, 0, d2.weight_bytes, 0x00020000);
     int a_base[A_IT], a_mask[A_IT], a_voff[A_IT];
     const int pitch2 = d1.in_pitch * 2;
+    {
+        PixWalk pw;
+        pw.init(m0 + wave * A_IT * 8 + srow, HW, W);
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + (wave * A_IT + i) * 8 + srow;
-        a_mask[i] = 0;
-        a_base[i] = 0;
-        if (m < Mg) {
-            const int b = m / HW, p = m - b * HW;
-            const int oy = p / W, ox = p - oy * W;
-            const int iy0 = oy - 1, ix0 = ox - 1;
-            int mask = 0;
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + (wave * A_IT + i) * 8 + srow;
+            a_mask[i] = 0;
+            a_base[i] = 0;
+            if (m < Mg) {
+                const int iy0 = pw.oy - 1, ix0 = pw.ox - 1;
+                int mask = 0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) mask |= (((unsigned)(iy0 + k) < (unsigned)H) << k) | (((unsigned)(ix0 + k) < (unsigned)W) << (8 + k));
-            a_mask[i] = mask;
-            a_base[i] = (int)((G1.in_off + (int64_t)b * G1.in_bstride) * 2) + gchunk * 16 + (iy0 * W + ix0) * pitch2;
+                for (int k = 0; k < 3; ++k) mask |= (((unsigned)(iy0 + k) < (unsigned)H) << k) | (((unsigned)(ix0 + k) < (unsigned)W) << (8 + k));
+                a_mask[i] = mask;
+                a_base[i] = (int)((G1.in_off + (int64_t)pw.b * G1.in_bstride) * 2) + gchunk * 16 + (iy0 * W + ix0) * pitch2;
+            }
+            if (i + 1 < A_IT) pw.advance(8, H, W);
         }
     }
     constexpr int Ktot1 = 9 * CMID;
@@ -943,10 +993,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
     // issued them itself (load -> wait -> add -> store, twice per workgroup) it was the longest phase of this HBM-bound
     // kernel: 20.7 of 29.8 us per workgroup at C = 64.
     RowAddr ra[MF2];
+    {
+        PixWalk pw;
+        pw.init(m0 + wm2 * (BM / P2M) + frow, HW, W);
+        const PixWalk first = {0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < MF2; ++i) {
-        const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
-        ra[i] = row_addr(d2, m < Mg ? m : 0, HW, W, H, G2.H_res, G2.W_res, G2.out_off, G2.out_bstride, G2.res_off, G2.res_bstride);
+        for (int i = 0; i < MF2; ++i) {
+            const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
+            ra[i] = row_addr_at(d2, m < Mg ? pw : first, W, H, G2.H_res, G2.W_res, G2.out_off, G2.out_bstride, G2.res_off, G2.res_bstride);
+            if (i + 1 < MF2) pw.advance(16, H, W);
+        }
     }
     const scalar* res = (const scalar*)d2.residual;
     vec8 rpre[MF2][NF2 / 2];

@@ -80,10 +80,17 @@ if __name__ == '__main__':
         # needs a library built with -DGPP_STAMPS (GPP_LIB=...): where does the per-tile time go?
         import numpy as np
         dev = torch.device('cuda')
-        for name, shp, cin, cout, k, tile, f32 in (('reg 3x3 512->512', PYR, 512, 512, 3, 256256, False),
-                                                   ('C3_reduced 1x1 512->512', PYR[:1], 512, 512, 1, 1192256, False),
-                                                   ('cls 3x3 256->256', PYR, 256, 256, 3, 1192256, False),
-                                                   ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3, 96128, False)):
+        shapes = (('reg 3x3 512->512', PYR, 512, 512, 3, 256256, False),
+                  ('C3_reduced 1x1 512->512', PYR[:1], 512, 512, 1, 1192256, False),
+                  ('cls 3x3 256->256', PYR, 256, 256, 3, 1192256, False),
+                  ('res4 2b 3x3 256->256', [(26, 84)], 256, 256, 3, 96128, False))
+        if len(sys.argv) > 3 and sys.argv[3] == 'small':      # the 1x1 layers of res3 / res4 / res5
+            shapes = (('res4 2a 1x1 1024->256', [(26, 84)], 1024, 256, 1, 96128, False),
+                      ('res4 2c 1x1 256->1024', [(26, 84)], 256, 1024, 1, 64128, False),
+                      ('res5 2a 1x1 2048->512', [(13, 42)], 2048, 512, 1, 64128, False),
+                      ('res5 2c 1x1 512->2048', [(13, 42)], 512, 2048, 1, 160128, False),
+                      ('res3 2a 1x1 512->128', [(51, 167)], 512, 128, 1, 160128, False))
+        for name, shp, cin, cout, k, tile, f32 in shapes:
             tdt = C.torch_dtype('bf16')
             total = sum(h * w for h, w in shp)
             x = (torch.randn((B, total, cin), device=dev) * 0.5).to(tdt)
