@@ -139,8 +139,15 @@ constexpr int kOutOfRange = (int)0x80000000;
         if ((d.reserved & 16) && wave == 0 && lane == 0)                                                      \
             ((unsigned long long*)d.zero_page)[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+#define GPP_STAMP_END()                                                                                       \
+    do {                                                                                                      \
+        GPP_STAMP(3);                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        GPP_STAMP(4);                                                                                         \
+    } while (0)
 #else
 #define GPP_STAMP(k) do { } while (0)
+#define GPP_STAMP_END() do { } while (0)
 #endif
 
 // Bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous tile range.
@@ -722,6 +729,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                     finish8_pre<DT>(d, v, n0 + wn * COLS + jj * 32 + fq * 8, ra_pre[i].obase, true, rpre[i][jj]);
                 }
             }
+            GPP_STAMP_END();
             return;
         }
         if (use_pre) {
@@ -742,8 +750,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                     finish8_pre<DT>(d, v, n, ra_pre[i].obase, true, rpre[i][jj]);
                 }
             }
-            GPP_STAMP(3);
-            GPP_STAMP(4);
+            GPP_STAMP_END();
             return;
         }
     }
@@ -767,6 +774,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             p += 16;
             while (p >= HoWo) { p -= HoWo; ++b; }
         }
+        GPP_STAMP_END();
         return;
     }
     PixWalk pwe;
@@ -791,11 +799,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             finish8<DT>(d, v, n, ra.obase, rrow);
         }
     }
-    GPP_STAMP(3);
-#ifdef GPP_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    GPP_STAMP(4);
+    GPP_STAMP_END();
 }
 
 template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>

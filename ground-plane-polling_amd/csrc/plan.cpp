@@ -104,6 +104,11 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
                 rc = gpp_stem_conv7x7_bn_relu_mfma(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
             break;
         }
+        case GPP_OP_STEM_POOL: {
+            const gpp_stem_desc* d = (const gpp_stem_desc*)op.desc;
+            rc = gpp_stem_pool_fused_mfma(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
+            break;
+        }
         case GPP_OP_MAXPOOL: {
             const gpp_pool_desc* d = (const gpp_pool_desc*)op.desc;
             rc = gpp_maxpool3x3s2_same(d->in, d->out, d->dtype, d->B, d->H, d->W, d->C, stream);

@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "gpp.h"
 
 namespace {
@@ -222,6 +224,170 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
     }
 }
 
+// ---- MFMA stem fused with pool1 -------------------------------------------------------------------
+// conv1 + bn_conv1 + ReLU + the 3x3 stride-2 'same' max-pool in one launch: the (B, Ho, Wo, 64) conv map -- 137 MB at
+// B = 8, 402 x 1333, written by the stem and read back by the pool -- never exists.  A persistent workgroup of 8
+// wavefronts marches DOWN a strip of 64 conv columns (31 pooled columns), 8 conv rows (one per wavefront, the matrix work
+// of stem_mfma_kernel) = 4 pooled rows per step.  The rounded conv rows go to a ring of 9 rows in LDS: pooled row py needs
+// conv rows 2 py - pt .. 2 py - pt + 2, so the last row of a step is the first of the next and is CARRIED in the ring,
+// not recomputed; a workgroup that starts in the middle of a strip computes just that one row first (a "pre-step" of one
+// wavefront).  Steps are numbered (image, strip, row block) with the row block fastest and cut into gridDim.x
+// contiguous, equally long ranges.  Pooling compares the stored (rounded) values, as maxpool_kernel does on the map the
+// unfused stem stores: the result is bit-identical to the two launches.
+// FP_ROWS = conv rows per step = wavefronts per workgroup: 8 (512 threads, 118 KB of LDS, one workgroup per CU) or 4 (256 threads,
+// 79.6 KB, two per CU).
+constexpr int FP_PCOLS = 31;                      // pooled columns per strip: conv columns 2j .. 2j + 2 <= 62 of the 64
+constexpr int FP_ROW_BYTES = 64 * 64 * 2;         // one conv row of a strip: 64 pixels x 64 channels, 16-bit
+constexpr int FP_W_BYTES = 64 * MW_PITCH * 2;
+constexpr int fp_lds(int rows) { return FP_W_BYTES + (rows * 2 + 5) * MP_PITCH * 2 + (rows + 1) * FP_ROW_BYTES; }
+
+template <typename scalar, typename vec8, int FP_ROWS>
+__global__ __launch_bounds__(64 * FP_ROWS, 8 / FP_ROWS) void stem_pool_mfma_kernel(const float* __restrict__ in, const _Float16* __restrict__ w,
+                                                                const float* __restrict__ bias, scalar* __restrict__ out,
+                                                                int B, int H, int W, int Ho, int Wo, int Hp, int Wp, int pt, int pl)
+{
+    constexpr int FP_PATCH_ROWS = FP_ROWS * 2 + 5;    // input rows under the conv rows of a step
+    constexpr int FP_RING = FP_ROWS + 1;              // conv rows resident in LDS
+    constexpr int FP_P_BYTES = FP_PATCH_ROWS * MP_PITCH * 2;
+    constexpr int NT = 64 * FP_ROWS, PR = FP_ROWS / 2;   // threads; pooled rows per step
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    _Float16* s_w = (_Float16*)fsm;
+    _Float16* s_p = (_Float16*)(fsm + FP_W_BYTES);
+    unsigned char* s_c = fsm + FP_W_BYTES + FP_P_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 64 * MW_PITCH / 8; e += NT) ((uint4*)s_w)[e] = ((const uint4*)w)[e];
+    const int n_strips = (Wp + FP_PCOLS - 1) / FP_PCOLS, n_blocks = (Hp + PR - 1) / PR;
+    const int64_t total = (int64_t)B * n_strips * n_blocks;
+    const int lo = (int)(total * blockIdx.x / gridDim.x), hi = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int frow = lane & 15, fq = lane >> 4;
+    float bias_v[2][8];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias_v[jj][e] = bias[jj * 32 + fq * 8 + e];
+
+    constexpr int PATCH_PAIRS = FP_PATCH_ROWS * (MP_PITCH / 2);
+    constexpr int PATCH_IT = (PATCH_PAIRS + NT - 1) / NT;
+    float patch[PATCH_IT][2];
+    // step idx = ((b * n_strips) + s) * n_blocks + t; a pre-step of step (b, s, t) is row block t - 1, last wavefront only
+    auto load_patch = [&](int idx, bool pre) {
+        const int t = idx % n_blocks, bs = idx / n_blocks;
+        const int sidx = bs % n_strips, b = bs / n_strips;
+        const int tt = pre ? t - 1 : t;
+        const int iy0 = (FP_ROWS * tt - pt + 1) * 2 - 3, ix0 = (2 * FP_PCOLS * sidx - pl) * 2 - 3;
+        const float* img = in + (size_t)b * H * W * 3;
+#pragma unroll
+        for (int it = 0; it < PATCH_IT; ++it) {
+            const int e = tid + it * NT;
+            const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
+            const int iy = iy0 + pr;
+            const int x0 = ix0 * 3 + c2;
+            float v0 = 0.0f, v1 = 0.0f;
+            if (e < PATCH_PAIRS && (unsigned)iy < (unsigned)H) {
+                const float* rowp = img + (size_t)iy * W * 3;
+                if (x0 >= 0 && x0 < W * 3) v0 = rowp[x0];
+                if (x0 + 1 >= 0 && x0 + 1 < W * 3) v1 = rowp[x0 + 1];
+            }
+            patch[it][0] = v0;
+            patch[it][1] = v1;
+        }
+    };
+    // the carried row of the first step of a range comes from nobody: compute it, unless it is the padding row above the map
+    auto needs_pre = [&](int idx, bool first) { return (idx % n_blocks) == 0 ? (pt == 0) : first; };
+    int idx = lo;
+    bool pre = lo < hi && needs_pre(lo, true);
+    if (lo < hi) load_patch(idx, pre);
+    while (idx < hi) {
+        const int t = idx % n_blocks, bs = idx / n_blocks;
+        const int sidx = bs % n_strips, b = bs / n_strips;
+        const int tt = pre ? t - 1 : t;
+        __syncthreads();                                     // the previous step's readers are done with s_p and the ring
+#pragma unroll
+        for (int it = 0; it < PATCH_IT; ++it) {
+            const int e = tid + it * NT;
+            const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
+            if (e < PATCH_PAIRS) *(f16x2*)(s_p + pr * MP_PITCH + c2) = (f16x2){(_Float16)patch[it][0], (_Float16)patch[it][1]};
+        }
+        __syncthreads();
+        const int nidx = pre ? idx : idx + 1;
+        const bool npre = pre ? false : (nidx < hi && needs_pre(nidx, false));
+        if (nidx < hi) load_patch(nidx, npre);
+        if (!pre || wave == FP_ROWS - 1) {
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) {
+                f16x8 wf[4], xf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = *(const f16x8*)(s_w + (j * 16 + frow) * MW_PITCH + kh * 32 + fq * 8);
+                const _Float16* prow = s_p + (wave * 2 + kh) * MP_PITCH + fq * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f16x2* src = (const f16x2*)(prow + (i * 16 + frow) * 6);
+                    const f16x2 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+                    xf[i] = (f16x8){p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            }
+            // conv row FP_ROWS tt - pt + 1 + wave -> ring slot (row + pt) mod FP_RING; 16-byte chunks XOR-swizzled by the pixel
+            unsigned char* crow = s_c + ((FP_ROWS * tt + 1 + wave + FP_RING) % FP_RING) * FP_ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int px = i * 16 + frow;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    vec8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (scalar)fmaxf(acc[i][2 * jj][e] + bias_v[jj][e], 0.0f);
+                        v[4 + e] = (scalar)fmaxf(acc[i][2 * jj + 1][e] + bias_v[jj][4 + e], 0.0f);
+                    }
+                    *(vec8*)(crow + px * 128 + (((jj * 4 + fq) ^ (px & 7)) << 4)) = v;
+                }
+            }
+        }
+        if (!pre) {
+            __syncthreads();
+            const int c0 = 2 * FP_PCOLS * sidx - pl;
+            for (int item = tid; item < PR * FP_PCOLS * 8; item += NT) {
+                const int c8 = item & 7, q = item >> 3;
+                const int k = q / FP_PCOLS, j = q - k * FP_PCOLS;
+                const int py = PR * t + k, px = FP_PCOLS * sidx + j;
+                if (py >= Hp || px >= Wp) continue;
+                float m[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) m[c] = -INFINITY;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = FP_ROWS * t - pt + 2 * k + dy;
+                    if ((unsigned)r >= (unsigned)Ho) continue;
+                    const unsigned char* crow = s_c + ((FP_ROWS * t + 2 * k + dy) % FP_RING) * FP_ROW_BYTES;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int cr = 2 * j + dx;
+                        if ((unsigned)(c0 + cr) >= (unsigned)Wo) continue;
+                        const vec8 v = *(const vec8*)(crow + cr * 128 + ((c8 ^ (cr & 7)) << 4));
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) m[c] = fmaxf(m[c], (float)v[c]);
+                    }
+                }
+                vec8 o;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = (scalar)m[c];
+                *(vec8*)(out + (((size_t)b * Hp + py) * Wp + px) * 64 + c8 * 8) = o;
+            }
+        }
+        idx = nidx;
+        pre = npre;
+    }
+}
+
 // 3x3 stride-2 max-pool, TF 'same' (pad_before = pad_total / 2, padding never wins)
 template <typename scalar, typename vec8>
 __global__ __launch_bounds__(256) void maxpool_kernel(const scalar* __restrict__ in, scalar* __restrict__ out,
@@ -341,6 +507,48 @@ extern "C" int gpp_stem_conv7x7_bn_relu_mfma(const float* in, const void* packed
         stem_mfma_kernel<_Float16, f16x8><<<grid, 256, 0, st>>>(in, (const _Float16*)packed_weight_f16, bias, (_Float16*)out, B, H, W, Ho, Wo);
     else
         return GPP_ERR_UNSUPPORTED;
+    return result();
+}
+
+extern "C" int gpp_stem_pool_fused_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
+                                        int dtype, int B, int H, int W, void* stream)
+{
+    if (!in || !packed_weight_f16 || !bias || !out || B <= 0 || H <= 0 || W <= 0) return GPP_ERR_BAD_ARG;
+    if (((uintptr_t)out | (uintptr_t)packed_weight_f16) & 15) return GPP_ERR_ALIGN;
+    if (dtype != GPP_BF16 && dtype != GPP_F16) return GPP_ERR_UNSUPPORTED;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const int Hp = (Ho + 1) / 2, Wp = (Wo + 1) / 2;
+    const int pt = ((Hp - 1) * 2 + 3 - Ho > 0 ? (Hp - 1) * 2 + 3 - Ho : 0) / 2;
+    const int pl = ((Wp - 1) * 2 + 3 - Wo > 0 ? (Wp - 1) * 2 + 3 - Wo : 0) / 2;
+    // 8 conv rows per step, one workgroup per CU; GPP_STEM_POOL_ROWS=4: 4 rows, two workgroups per CU (measured equal:
+    // 81 against 82 us at B = 8, 402 x 1333, tools/stem_time.py -- the kernel is bound by its LDS reads and patch loads, not by
+    // the order of its phases)
+    static const int rows = [] { const char* e = getenv("GPP_STEM_POOL_ROWS"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    const int pr = rows / 2;
+    const int64_t total = (int64_t)B * ((Wp + FP_PCOLS - 1) / FP_PCOLS) * ((Hp + pr - 1) / pr);
+    if (total >= (1LL << 30)) return GPP_ERR_UNSUPPORTED;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return GPP_ERR_UNSUPPORTED;
+    const int64_t slots = (int64_t)cus * (8 / rows);                             // persistent workgroups
+    const unsigned grid = (unsigned)(total < slots ? total : slots);
+    hipStream_t st = (hipStream_t)stream;
+    // hipFuncSetAttribute is per device: remember the devices each instantiation has been configured on
+    static std::atomic<uint64_t> done[4];
+    const int which = (dtype == GPP_BF16 ? 0 : 1) + (rows == 8 ? 0 : 2);
+    const void* fns[4] = {(const void*)stem_pool_mfma_kernel<__bf16, bf16x8, 8>, (const void*)stem_pool_mfma_kernel<_Float16, f16x8, 8>,
+                          (const void*)stem_pool_mfma_kernel<__bf16, bf16x8, 4>, (const void*)stem_pool_mfma_kernel<_Float16, f16x8, 4>};
+    const int lds = fp_lds(rows);
+    if (!(done[which].load(std::memory_order_acquire) & (1ull << (dev & 63)))) {
+        const hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        done[which].fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const _Float16* wp = (const _Float16*)packed_weight_f16;
+    if (which == 0) stem_pool_mfma_kernel<__bf16, bf16x8, 8><<<grid, 512, lds, st>>>(in, wp, bias, (__bf16*)out, B, H, W, Ho, Wo, Hp, Wp, pt, pl);
+    else if (which == 1) stem_pool_mfma_kernel<_Float16, f16x8, 8><<<grid, 512, lds, st>>>(in, wp, bias, (_Float16*)out, B, H, W, Ho, Wo, Hp, Wp, pt, pl);
+    else if (which == 2) stem_pool_mfma_kernel<__bf16, bf16x8, 4><<<grid, 256, lds, st>>>(in, wp, bias, (__bf16*)out, B, H, W, Ho, Wo, Hp, Wp, pt, pl);
+    else stem_pool_mfma_kernel<_Float16, f16x8, 4><<<grid, 256, lds, st>>>(in, wp, bias, (_Float16*)out, B, H, W, Ho, Wo, Hp, Wp, pt, pl);
     return result();
 }
 

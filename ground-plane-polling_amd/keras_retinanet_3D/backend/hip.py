@@ -85,6 +85,8 @@ def _declare(lib):
     lib.gpp_stem_conv7x7_bn_relu_mfma.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.gpp_stem_pack_weights_f16.restype = c_int
     lib.gpp_stem_pack_weights_f16.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.gpp_stem_pool_fused_mfma.restype = c_int
+    lib.gpp_stem_pool_fused_mfma.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.gpp_maxpool3x3s2_same.restype = c_int
     lib.gpp_maxpool3x3s2_same.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.gpp_relu.restype = c_int

@@ -89,6 +89,7 @@ OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4,
 OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT = 8, 9, 10
 OP_TAIL_NEXT = 11
 OP_DETECT_OSF = 12
+OP_STEM_POOL = 13
 DETECT_OPS = (OP_DETECT, OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT, 12)
 OP_JOIN, OP_SYNC = 0x10000, 0x20000
 
@@ -248,14 +249,22 @@ class RetinaNet3D(object):
 
         # ---- stem: conv1 + bn_conv1 + relu, pool1
         H1, W1 = (H + 6 - 7) // 2 + 1, (Wd + 6 - 7) // 2 + 1
-        stem = fmap(H1, W1, 64)
-        d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
-                     C.gpp_storage_dtype(self.dtype), B, H, Wd)
-        plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
-        plan.stem_out = stem
         H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
         x = fmap(H2, W2, 64)
-        plan.add(OP_MAXPOOL, PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_storage_dtype(self.dtype), B, H1, W1, 64, 0), 'pool1')
+        if self.esz == 2 and os.environ.get('GPP_FUSE_STEM_POOL', '1') != '0':
+            # 16-bit types: conv1 + bn_conv1 + relu + pool1 in one launch, the (B, H1, W1, 64) conv map is never stored
+            # (bit-identical to the two launches: tests/test_stem_gpu.py)
+            d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), x.buf.data_ptr(),
+                         C.gpp_storage_dtype(self.dtype), B, H, Wd)
+            plan.add(OP_STEM_POOL, d, 'conv1+pool1', flops=2.0 * B * H1 * W1 * 147 * 64)
+            plan.stem_out = None
+        else:
+            stem = fmap(H1, W1, 64)
+            d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
+                         C.gpp_storage_dtype(self.dtype), B, H, Wd)
+            plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
+            plan.stem_out = stem
+            plan.add(OP_MAXPOOL, PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_storage_dtype(self.dtype), B, H1, W1, 64, 0), 'pool1')
         plan.pool_out = x
 
         # ---- bottleneck stages (keras_resnet bottleneck_2d: stride on the first 1x1).
@@ -322,7 +331,7 @@ class RetinaNet3D(object):
                     xs = y_
             feats.append(x)
         _, C3, C4, C5 = feats
-        plan.features = {'stem': stem, 'C2': feats[0], 'C3': C3, 'C4': C4, 'C5': C5}
+        plan.features = {'stem': plan.stem_out, 'C2': feats[0], 'C3': C3, 'C4': C4, 'C5': C5}
 
         # ---- FPN into one pyramid tensor (B, sum(H_l*W_l), 512)
         shapes = anchor_utils.pyramid_shapes((H, Wd))

@@ -212,6 +212,11 @@ int gpp_stem_pack_weights_f16(const float* host_weight_147x64, void* host_packed
 int gpp_stem_conv7x7_bn_relu_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
                                   int dtype, int B, int H, int W, void* stream);
 int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B, int H, int W, int C, void* stream);
+/* conv1 + bn_conv1 + ReLU + pool1 in ONE launch (GPP_BF16 / GPP_F16): out is the POOLED map (B, Hp, Wp, 64), Hp = (Ho + 1)/2;
+ * the (B, Ho, Wo, 64) conv map is never written (137 MB at B = 8, 402 x 1333).  Bit-identical to
+ * gpp_stem_conv7x7_bn_relu_mfma followed by gpp_maxpool3x3s2_same (the max is taken over the rounded conv values). */
+int gpp_stem_pool_fused_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
+                             int dtype, int B, int H, int W, void* stream);
 int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream);
 /* batched form: image b reads `count` elements at in + b*in_bstride, writes out + b*out_bstride */
 int gpp_relu_strided(const void* in, int64_t in_bstride, void* out, int64_t out_bstride, int dtype, int B,
@@ -313,6 +318,7 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 #define GPP_OP_DETECT_EMIT 10
 #define GPP_OP_BOTTLENECK_TAIL_NEXT 11   /* gpp_tail_next_desc */
 #define GPP_OP_DETECT_OSF 12             /* gpp_detect_desc -> gpp_detect_osf_f32 */
+#define GPP_OP_STEM_POOL 13              /* gpp_stem_desc with out = the pooled map -> gpp_stem_pool_fused_mfma */
 /* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
    that forks from the caller's stream at the first op of that lane; `kind | GPP_OP_JOIN` on a lane-0 op makes it wait
    for every open lane (the end of the plan joins too).  The caller orders the ops so that each lane only depends on

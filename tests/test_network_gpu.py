@@ -378,7 +378,7 @@ def check_every_layer(backbone, dtype, fuse_next, batch, h, w, monkeypatch):
     (float32 storage, three bf16 products per float32 product) against the same float32 oracle: <= 2e-4 * rms + 1e-4 |oracle|.
     (tests/test_fullsize_gpu.py runs the same check at the BASELINE size 402x1333.) """
     import torch
-    from keras_retinanet_3D.models.retinanet import OP_CONV, OP_MAXPOOL, OP_RELU, OP_STEM, OP_TAIL, OP_TAIL_NEXT
+    from keras_retinanet_3D.models.retinanet import OP_CONV, OP_MAXPOOL, OP_RELU, OP_STEM, OP_STEM_POOL, OP_TAIL, OP_TAIL_NEXT
     monkeypatch.setenv('GPP_FUSE_NEXT', fuse_next)            # '1': tail launches that also compute the next block's branch2a
     model50 = models.load_model('synthetic:1234', backbone_name=backbone, dtype=dtype)
     weights = W.synthetic_weights(backbone, 1234)
@@ -432,6 +432,10 @@ def check_every_layer(backbone, dtype, fuse_next, batch, h, w, monkeypatch):
             model50.run_op(plan, index)
             compare(name, plan.stem_out, tr[('conv1', 0)])
             register(plan.stem_out, tr[('conv1', 0)])
+        elif kind == OP_STEM_POOL:                               # conv1 + pool1 in one launch: the max of the stored conv values
+            model50.run_op(plan, index)
+            compare(name, plan.pool_out, tr[('pool1', 0)])
+            register(plan.pool_out, tr[('pool1', 0)])
         elif kind == OP_MAXPOOL:
             feed(plan.stem_out)
             model50.run_op(plan, index)

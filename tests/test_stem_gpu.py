@@ -55,6 +55,43 @@ def test_maxpool_matches_torch(B, H, W, C):
     assert torch.equal(out.float().cpu(), ref)
 
 
+@pytest.mark.parametrize('dtype,tdt', [(hip.GPP_BF16, torch.bfloat16), (hip.GPP_F16, torch.float16)])
+@pytest.mark.parametrize('B,H,W', [(2, 37, 53), (1, 40, 56), (3, 38, 55), (1, 7, 9), (2, 96, 160), (1, 127, 211), (1, 270, 500), (2, 402, 1333)])
+def test_fused_stem_pool_equals_the_two_launches(B, H, W, dtype, tdt):
+    """ conv1 + bn + relu + pool1 in one launch == the MFMA stem followed by the max-pool, bit for bit: odd and even conv map
+    sizes (pool padding 1 / 0 on either axis, i.e. with and without the extra first row of a strip), maps narrower than one
+    strip and shorter than one row block, several strips / row blocks / images per persistent workgroup. """
+    g = torch.Generator().manual_seed(H * W + B)
+    x = torch.rand((B, H, W, 3), generator=g) * 255.0 - 120.0
+    k = torch.randn((7, 7, 3, 64), generator=g) * 0.05
+    bias = torch.randn((64,), generator=g)
+    dev = torch.device('cuda')
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Ho + 1) // 2, (Wo + 1) // 2
+    xd, bd = x.to(dev).contiguous(), bias.to(dev)
+    packed = hip.pack_stem_weights(k.reshape(147, 64).numpy(), dev)
+    conv = torch.full((B, Ho, Wo, 64), float('nan'), dtype=tdt, device=dev)
+    want = torch.full((B, Hp, Wp, 64), float('nan'), dtype=tdt, device=dev)
+    got = torch.full((B, Hp, Wp, 64), float('nan'), dtype=tdt, device=dev)
+    hip.check(hip.lib().gpp_stem_conv7x7_bn_relu_mfma(hip.ptr(xd), hip.ptr(packed), hip.ptr(bd), hip.ptr(conv), dtype, B, H, W, hip.stream_ptr()))
+    hip.check(hip.lib().gpp_maxpool3x3s2_same(hip.ptr(conv), hip.ptr(want), dtype, B, Ho, Wo, 64, hip.stream_ptr()))
+    hip.check(hip.lib().gpp_stem_pool_fused_mfma(hip.ptr(xd), hip.ptr(packed), hip.ptr(bd), hip.ptr(got), dtype, B, H, W, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    a, b = got.view(torch.int16).cpu(), want.view(torch.int16).cpu()
+    assert not torch.isnan(want.float()).any()
+    assert torch.equal(a, b), 'differs at {} of {} elements'.format(int((a != b).sum()), a.numel())
+
+
+def test_fused_stem_pool_rejects_float32():
+    dev = torch.device('cuda')
+    x = torch.zeros((1, 16, 16, 3), device=dev)
+    w = torch.zeros((64 * 232,), dtype=torch.float16, device=dev)
+    b = torch.zeros((64,), device=dev)
+    out = torch.zeros((1, 4, 4, 64), device=dev)
+    assert hip.lib().gpp_stem_pool_fused_mfma(hip.ptr(x), hip.ptr(w), hip.ptr(b), hip.ptr(out), hip.GPP_F32, 1, 16, 16, hip.stream_ptr()) == -4
+    assert hip.lib().gpp_stem_pool_fused_mfma(None, hip.ptr(w), hip.ptr(b), hip.ptr(out), hip.GPP_BF16, 1, 16, 16, hip.stream_ptr()) == -1
+
+
 def test_relu():
     dev = torch.device('cuda')
     x = torch.randn((3, 7, 21, 512)).to(torch.bfloat16).to(dev)

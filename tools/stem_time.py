@@ -15,6 +15,18 @@ e0.record()
 for _ in range(50): run()
 e1.record(); torch.cuda.synchronize()
 print(os.environ.get('GPP_STEM_WGS_PER_CU','2'), 'WGs/CU: stem %.1f us'%(e0.elapsed_time(e1)*20))
+pooled=torch.empty((B,101,334,64),dtype=torch.bfloat16,device='cuda')
+def timed(fn, n=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)*1000.0/n
+def pool(): hip.check(hip.lib().gpp_maxpool3x3s2_same(hip.ptr(out),hip.ptr(pooled),1,B,201,667,64,hip.stream_ptr()))
+def both(): run(); pool()
+def fused(): hip.check(hip.lib().gpp_stem_pool_fused_mfma(hip.ptr(x),hip.ptr(w),hip.ptr(b),hip.ptr(pooled),1,B,H,W,hip.stream_ptr()))
+print('pool alone %.1f us; stem + pool %.1f us; fused stem+pool %.1f us' % (timed(pool), timed(both), timed(fused)))
 
 if hasattr(hip.lib(), 'gpp_debug_set_stem_stamps'):
     import ctypes
