@@ -459,6 +459,21 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         }
     }
 
+    // bias of this lane's output channels: the plain tiles fetch it here, under the main loop (their workgroups live 7-17 us
+    // and used to pay this load's latency in the epilogue); the pipelined tiles have no registers to spare and fetch it there
+    constexpr int COLS = BN / WN;                        // output channels owned by this wave
+    static_assert(NF % 2 == 0, "N tiles come in interleaved pairs");
+    float bias_v[NF / 2][8];
+    auto load_bias = [&]() {
+#pragma unroll
+        for (int jj = 0; jj < NF / 2; ++jj) {
+            const int n = n0 + wn * COLS + jj * 32 + (lane >> 4) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias_v[jj][e] = (d.bias && n + e < d.C_out) ? d.bias[n + e] : 0.0f;
+        }
+    };
+    if constexpr (!PIPE) load_bias();
+
     GPP_STAMP(1);
     // ---- main loop.  Ring of STAGES buffers, PF = STAGES-1 K-steps of LDS-DMA in flight; one raw
     // s_barrier per K-step.  At the top of step ks a counted vmcnt retires this wave's loads of
@@ -684,8 +699,6 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     // (row 16h + 4q + r of every 32-row group = output channel 8q + 4h + r), hence tiles 2jj and
     // 2jj+1 together give this lane EIGHT CONSECUTIVE output channels n = n0 + 32jj + 8fq + 0..7:
     // one 16-byte store (two for float32 output), no LDS round trip.
-    constexpr int COLS = BN / WN;                        // output channels owned by this wave
-    static_assert(NF % 2 == 0, "N tiles come in interleaved pairs");
     if (nsplit > 1) {
         // raw float32 partial tile -> d.partial[split][mt*BM + row][nt*BN + col]
         const int64_t rows_pad = (int64_t)d.partial_rows, npad = (int64_t)n_tiles * BN;
@@ -707,13 +720,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     // runs the epilogue without per-lane conditions (the general form costs ~280 exec-mask branches per wavefront: 6 us of a
     // 256 x 256 tile's life, a quarter of a 18-K-step tile's) and walks the output rows instead of dividing per row.
     const bool interior = (m0 + BM <= Mg) && (n0 + BN <= d.C_out) && ((d.C_out & 7) == 0);
-    float bias_v[NF / 2][8];
-#pragma unroll
-    for (int jj = 0; jj < NF / 2; ++jj) {
-        const int n = n0 + wn * COLS + jj * 32 + fq * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias_v[jj][e] = (d.bias && n + e < d.C_out) ? d.bias[n + e] : 0.0f;
-    }
+    if constexpr (PIPE) load_bias();
     if constexpr (RESPRE) {
         if (use_pre && interior) {
 #pragma unroll

@@ -129,7 +129,14 @@ class FramePipeline(object):
 
     def _collect(self, slot):
         if not self.pinned:
-            slot['done'].synchronize()
-            return D.unpack_outputs(slot['d_packed'].cpu().numpy()), slot['scale']
+            # the blocking copy runs on the DOWNLOAD stream, which waits for this batch's `done` event only: issued on the
+            # compute stream (as a plain .cpu() is) it would wait for every batch enqueued since -- the host would then
+            # enqueue the next batch into an idle GPU (measured: 92.7 % of the resident rate that way)
+            torch = self.torch
+            with torch.cuda.stream(self.down_stream):
+                self.down_stream.wait_event(slot['done'])
+                host = slot['d_packed'].cpu()
+                slot['downloaded'].record(self.down_stream)
+            return D.unpack_outputs(host.numpy()), slot['scale']
         slot['downloaded'].synchronize()
         return D.unpack_outputs(slot['h_packed'].numpy().copy()), slot['scale']
