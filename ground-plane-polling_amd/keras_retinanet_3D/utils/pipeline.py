@@ -25,7 +25,7 @@ class FramePipeline(object):
     by a second stream into pinned memory).  That is what the reference's timer brackets -- feed + run + fetch,
     bin/run_network.py:108-111 -- in its streaming form; the compute stream never waits for the host. """
 
-    def __init__(self, model, depth=4, graph=False, pinned=False):
+    def __init__(self, model, depth=4, graph=False, pinned=False, inline=False):
         import torch
         self.model = model
         self.torch = torch
@@ -36,6 +36,14 @@ class FramePipeline(object):
         # DMA now and then, in either direction -- so both stay off
         self.graph = bool(graph)
         self.pinned = bool(pinned)
+        # How the results leave (measured on MI355X with tools/bench_pipeline.py, 8 binary-noise frames per batch, three runs of 60
+        # batches each; the plan alone on the same frames resident in HBM: 1621 images/s):
+        #   default: a blocking .cpu() of the packed tensor on the compute stream          1594-1606 (98-99 % of resident), steady
+        #   inline=True: the compute stream copies into a pinned buffer behind the pack kernel, the host waits for that copy's
+        #                event only                                                         1515-1600, occasional 7-8 ms batches
+        #   pinned=True: a third stream copies into a pinned buffer                         1471-1560, occasional 20 ms batches
+        # (re-used pinned host buffers stall this platform's DMA now and then), so the plain form stays the default
+        self.inline = bool(inline)
         self.copy_stream = torch.cuda.Stream()
         self.down_stream = torch.cuda.Stream()
         self.slots = None
@@ -53,7 +61,7 @@ class FramePipeline(object):
                 'd_pinv': torch.empty(tuple(P_inv.shape), dtype=torch.float32, device=dev),
                 'd_planes': torch.empty(tuple(planes.shape), dtype=torch.float32, device=dev),
                 'd_packed': torch.empty((B, 100, D.PACK_WIDTH), dtype=torch.float32, device=dev),
-                'h_packed': torch.empty((B, 100, D.PACK_WIDTH), dtype=torch.float32).pin_memory() if self.pinned else None,
+                'h_packed': torch.empty((B, 100, D.PACK_WIDTH), dtype=torch.float32).pin_memory() if (self.pinned or self.inline) else None,
                 'uploaded': torch.cuda.Event(), 'consumed': torch.cuda.Event(), 'done': torch.cuda.Event(),
                 'downloaded': torch.cuda.Event(),
             })
@@ -87,7 +95,10 @@ class FramePipeline(object):
                                                   [int(outs[0].shape[0]), int(outs[0].shape[1]), hip.ptr(slot['d_packed']),
                                                    hip.stream_ptr()])), 'gpp_pack_detections')
         slot['done'].record(cur)
-        if self.pinned:
+        if self.inline:
+            slot['h_packed'].copy_(slot['d_packed'], non_blocking=True)
+            slot['downloaded'].record(cur)
+        elif self.pinned:
             with torch.cuda.stream(self.down_stream):
                 self.down_stream.wait_event(slot['done'])
                 slot['h_packed'].copy_(slot['d_packed'], non_blocking=True)
@@ -128,15 +139,11 @@ class FramePipeline(object):
             yield self._collect(pending.pop(0))
 
     def _collect(self, slot):
+        if self.inline:
+            slot['downloaded'].synchronize()                        # this batch's copy only: later batches keep running
+            return D.unpack_outputs(slot['h_packed'].numpy().copy()), slot['scale']
         if not self.pinned:
-            # the blocking copy runs on the DOWNLOAD stream, which waits for this batch's `done` event only: issued on the
-            # compute stream (as a plain .cpu() is) it would wait for every batch enqueued since -- the host would then
-            # enqueue the next batch into an idle GPU (measured: 92.7 % of the resident rate that way)
-            torch = self.torch
-            with torch.cuda.stream(self.down_stream):
-                self.down_stream.wait_event(slot['done'])
-                host = slot['d_packed'].cpu()
-                slot['downloaded'].record(self.down_stream)
-            return D.unpack_outputs(host.numpy()), slot['scale']
+            slot['done'].synchronize()
+            return D.unpack_outputs(slot['d_packed'].cpu().numpy()), slot['scale']
         slot['downloaded'].synchronize()
         return D.unpack_outputs(slot['h_packed'].numpy().copy()), slot['scale']
