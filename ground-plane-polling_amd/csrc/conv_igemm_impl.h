@@ -355,9 +355,14 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     const int nk_total = d.KH * d.KW * cpt;
     // split-K: blockIdx.y owns K-steps [ks0, ks0 + nk); partial sums go to d.partial, the epilogue runs
     // in splitk_reduce_kernel
+    // (32-bit: nk_total * nsplit is a few thousand at most; the unsplit case -- almost every launch -- divides nothing.  The
+    // 64-bit divisions that stood here cost every workgroup of every layer a few hundred instructions of setup.)
     const int nsplit = gridDim.y, split = blockIdx.y;
-    const int ks0 = (int)((int64_t)nk_total * split / nsplit);
-    const int nk = (int)((int64_t)nk_total * (split + 1) / nsplit) - ks0;
+    int ks0 = 0, nk = nk_total;
+    if (nsplit > 1) {
+        ks0 = (int)((unsigned)(nk_total * split) / (unsigned)nsplit);
+        nk = (int)((unsigned)(nk_total * (split + 1)) / (unsigned)nsplit) - ks0;
+    }
 
     // ---- staging bookkeeping: this lane owns LDS chunk (row srow of each 8-row piece, slot lane&7)
     // and fetches source chunk gchunk = slot ^ srow (inverse of the read swizzle).  Byte offsets are
@@ -382,10 +387,12 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             a_base[i] = 0;
             if (m < Mg) {
                 const int iy0 = pw.oy * d.stride - d.pad_top, ix0 = pw.ox * d.stride - d.pad_left;
-                int mask = 0;
-                for (int k = 0; k < d.KH; ++k) mask |= ((unsigned)(iy0 + k) < (unsigned)H_in) << k;
-                for (int k = 0; k < d.KW; ++k) mask |= ((unsigned)(ix0 + k) < (unsigned)W_in) << (8 + k);
-                a_mask[i] = mask;
+                // bit k: input row iy0 + k inside the image = k in [max(0, -iy0), min(KH, H_in - iy0)); columns likewise (no loops)
+                const int rlo = max(0, -iy0), rhi = min(d.KH, max(0, H_in - iy0));
+                const int clo = max(0, -ix0), chi = min(d.KW, max(0, W_in - ix0));
+                const int rmask = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
+                const int cmask = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
+                a_mask[i] = rmask | (cmask << 8);
                 a_base[i] = (int)((in_off + (int64_t)pw.b * in_bs) * ESZ) + gchunk * 16 + (iy0 * W_in + ix0) * pitch2;
             }
             if (i + 1 < A_IT) pw.advance(8, H_out, W_out);
@@ -484,7 +491,8 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     // chunk re-read the same few input rows back to back, so they hit in the XCD's L2 instead of being
     // re-fetched across the fabric once per tap
     const int taps = d.KH * d.KW;
-    int cc = ks0 / taps, kw = (ks0 % taps) % d.KW, kh = (ks0 % taps) / d.KW, issued = 0, ibuf = 0;
+    int cc = 0, kw = 0, kh = 0, issued = 0, ibuf = 0;
+    if (ks0 != 0) { cc = ks0 / taps; kw = (ks0 % taps) % d.KW; kh = (ks0 % taps) / d.KW; }
     set_tap(kh, kw);
     auto issue_next = [&]() {
         stage(ibuf, cc, ks0 + issued);

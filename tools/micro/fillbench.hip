@@ -147,5 +147,16 @@ int main()
     run<4, 96, 128, 4, 0, 24>(bf, 256, 64, 0, "1 wg/CU 4 stages + work");
     run<4, 96, 128, 5, 0, 24>(bf, 256, 64, 0, "1 wg/CU 5 stages + work");
     run<8, 96 * 2, 128, 3, 0, 24>(bf, 256, 64, 0, "1 wg/CU 8 waves 192+128 3 stages + work");
+    // ---- does the K-step time follow the BYTES of a K-step?  (a 3x3 layer re-reads its activation rows once per tap: sharing a staged
+    // patch between taps would cut the activation bytes by 2/3 -- worth building only if the loop is bandwidth- and not latency-bound)
+    printf("== res4 2b shape (36 K-steps, 364 workgroups, 2 stages, barrier, + work): activation rows per K-step 96 / 64 / 32, weights 128\n");
+    run<4, 96, 128, 2, 0, 24>(bf, 364, 36, 0, "A 96 rows (today)");
+    run<4, 64, 128, 2, 0, 24>(bf, 364, 36, 0, "A 64 rows");
+    run<4, 32, 128, 2, 0, 24>(bf, 364, 36, 0, "A 32 rows (= patch shared by the 9 taps)");
+    run<4, 96, 64, 2, 0, 24>(bf, 364, 36, 0, "A 96 rows, weights 64");
+    run<4, 32, 32, 2, 0, 24>(bf, 364, 36, 0, "A 32 rows, weights 32");
+    printf("== res3 tail phase 1 shape (18 K-steps, 418 workgroups, 160 + 128 rows)\n");
+    run<4, 160, 128, 2, 0, 40>(bf, 418, 18, 0, "A 160 rows (today)");
+    run<4, 64, 128, 2, 0, 40>(bf, 418, 18, 0, "A 64 rows");
     return 0;
 }

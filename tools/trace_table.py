@@ -32,7 +32,7 @@ def short(k):
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>', k)
     if m:
         return 'igemm %sx%s w%sx%s s%s%s' % (m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), ' pipe' if m.group(7) in ('true', '1') else '')
-    for key in ('stem_mfma', 'stem_kernel', 'maxpool', 'relu', 'splitk_reduce', 'clear_counters', 'candidates', 'nms', 'emit_kernel', 'canonical_planes', 'poll'):
+    for key in ('stem_pool_mfma', 'stem_mfma', 'stem_kernel', 'maxpool', 'relu', 'splitk_reduce', 'clear_counters', 'candidates', 'nms', 'emit_kernel', 'canonical_planes', 'poll'):
         if key in k:
             return key
     return k[:40]
@@ -65,7 +65,7 @@ def main(path, backbone='resnet50', fused='0,1'):
             name = '  (split-K reduce)'
         else:
             name = short(k)
-        grp = 'stem+pool' if name in ('stem_mfma', 'stem_kernel', 'maxpool') else \
+        grp = 'stem+pool' if name in ('stem_pool_mfma', 'stem_mfma', 'stem_kernel', 'maxpool') else \
               'backbone' if name.startswith('res') else 'heads' if name[:3] in ('reg', 'dim', 'cls', 'hea') else \
               'decode+poll' if name in ('clear_counters', 'candidates', 'nms', 'emit_kernel', 'canonical_planes', 'poll') else \
               'fpn' if name[0] in 'CP' or name == 'relu' else 'other'
