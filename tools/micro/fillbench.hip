@@ -158,5 +158,12 @@ int main()
     printf("== res3 tail phase 1 shape (18 K-steps, 418 workgroups, 160 + 128 rows)\n");
     run<4, 160, 128, 2, 0, 40>(bf, 418, 18, 0, "A 160 rows (today)");
     run<4, 64, 128, 2, 0, 40>(bf, 418, 18, 0, "A 64 rows");
+    // ---- one more K-step in flight at an UNCHANGED number of workgroups per CU (smaller stages, three of them)
+    printf("== depth at equal occupancy: 36 K-steps, 364 workgroups, 2 workgroups per CU in every line\n");
+    run<4, 64, 128, 2, 0, 24>(bf, 364, 36, 24576, "64+128, 2 stages (padded to 2 wg/CU)");
+    run<4, 64, 128, 3, 0, 24>(bf, 364, 36, 0, "64+128, 3 stages");
+    run<4, 32, 128, 2, 0, 24>(bf, 364, 36, 40960, "32+128, 2 stages (padded to 2 wg/CU)");
+    run<4, 32, 128, 3, 0, 24>(bf, 364, 36, 16384, "32+128, 3 stages (padded to 2 wg/CU)");
+    run<4, 32, 128, 4, 0, 24>(bf, 364, 36, 0, "32+128, 4 stages");
     return 0;
 }
