@@ -30,6 +30,11 @@ int validate(const gpp_conv_desc& d)
 #ifndef GPP_STAMPS
     if (d.reserved != 0) return GPP_ERR_BAD_ARG;                    // diagnostic switches exist in -DGPP_STAMPS builds only
 #endif
+    if (d.reserved2 != 0 || (d.x3_split & ~(GPP_X3_IN | GPP_X3_OUT | GPP_X3_RES))) return GPP_ERR_BAD_ARG;
+    if (d.x3_split && d.dtype != GPP_BF16X3) return GPP_ERR_BAD_ARG;
+    if ((d.x3_split & GPP_X3_OUT) && (d.out_f32 || d.C_out % 32 != 0 || d.out_pitch % 32 != 0)) return GPP_ERR_UNSUPPORTED;
+    if ((d.x3_split & GPP_X3_IN) && d.in_pitch % 32 != 0) return GPP_ERR_UNSUPPORTED;
+    if ((d.x3_split & GPP_X3_RES) && (!d.residual || d.res_pitch % 32 != 0)) return GPP_ERR_UNSUPPORTED;
     const int oa = (d.out_f32 || f32_storage(d.dtype)) ? 4 : 8;        // output elements per 16 bytes
     if (d.in_pitch < d.C_in || d.in_pitch % va != 0) return GPP_ERR_ALIGN;
     if (d.out_pitch < d.C_out || d.out_pitch % oa != 0) return GPP_ERR_ALIGN;
@@ -44,6 +49,9 @@ int validate(const gpp_conv_desc& d)
         if ((G.in_off | G.in_bstride) % va != 0) return GPP_ERR_ALIGN;
         if (d.residual && ((G.res_off | G.res_bstride) % va != 0 || G.H_res <= 0 || G.W_res <= 0)) return GPP_ERR_ALIGN;
         if ((int64_t)d.batch * G.H_out * G.W_out >= (1LL << 31)) return GPP_ERR_UNSUPPORTED;
+        if ((d.x3_split & GPP_X3_OUT) && ((G.out_off | G.out_bstride) % 32 != 0)) return GPP_ERR_ALIGN;      // pre-split maps: whole 32-channel blocks
+        if ((d.x3_split & GPP_X3_IN) && ((G.in_off | G.in_bstride) % 32 != 0)) return GPP_ERR_ALIGN;
+        if ((d.x3_split & GPP_X3_RES) && ((G.res_off | G.res_bstride) % 32 != 0)) return GPP_ERR_ALIGN;
     }
     return GPP_OK;
 }

@@ -158,6 +158,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
+// GPP_BF16X3 pre-split maps (gpp_conv_desc.x3_split): channels n .. n + 7 (n a multiple of 8) of the pixel whose float32-sized
+// element offset is `base` live at byte (base + (n & ~31)) * 4 + (n & 31) * 2 (8 bf16 hi) and 64 bytes further (8 bf16 lo).
+__device__ __forceinline__ const char* x3_addr(const void* buf, int64_t base, int n)
+{
+    return (const char*)buf + ((base + (n & ~31)) << 2) + ((n & 31) << 1);
+}
+__device__ __forceinline__ void x3_unpack(const f32x4 hi_bits, const f32x4 lo_bits, float (&r)[8])
+{
+    union { f32x4 f; bf16x8 b; } h, l;
+    h.f = hi_bits;
+    l.f = lo_bits;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (float)h.b[e] + (float)l.b[e];
+}
+__device__ __forceinline__ void x3_store(void* buf, int64_t base, int n, const float (&v)[8])
+{
+    bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = (__bf16)v[e];
+        l[e] = (__bf16)(v[e] - (float)h[e]);
+    }
+    char* p = (char*)x3_addr(buf, base, n);
+    *(bf16x8*)p = h;
+    *(bf16x8*)(p + 64) = l;
+}
+
 // Finish 8 consecutive output channels of one output pixel: (+ residual through the optional TF
 // nearest resize) (+ ReLU), convert, store.  v already holds accumulator + bias.
 template <int DT>
@@ -167,6 +194,16 @@ __device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], i
     using vec8 = typename Elem<DT>::vec8;
     using scalar = typename Elem<DT>::scalar;
     const bool full = (n + 8 <= d.C_out);
+    if constexpr (DT == GPP_BF16X3) {
+        if (rrow && (d.x3_split & GPP_X3_RES)) {            // pre-split shortcut map (whole 8-channel groups by construction)
+            const char* p = x3_addr(rrow, 0, n);
+            float r[8];
+            x3_unpack(*(const f32x4*)p, *(const f32x4*)(p + 64), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+            rrow = nullptr;
+        }
+    }
     if (rrow) {
         if (full) {
             const vec8 rv = *(const vec8*)(rrow + n);
@@ -179,6 +216,12 @@ __device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], i
     if (d.relu) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+    }
+    if constexpr (DT == GPP_BF16X3) {
+        if (d.x3_split & GPP_X3_OUT) {                      // (validated: not out_f32, C_out a multiple of 32)
+            x3_store(d.out, obase, n, v);
+            return;
+        }
     }
     if (d.out_f32) {
         float* dst = (float*)d.out + obase + n;
@@ -206,12 +249,30 @@ __device__ __forceinline__ void finish8_pre(const gpp_conv_desc& d, float (&v)[8
     using vec8 = typename Elem<DT>::vec8;
     using scalar = typename Elem<DT>::scalar;
     if (has_res) {
+        bool done = false;
+        if constexpr (DT == GPP_BF16X3) {
+            if (d.x3_split & GPP_X3_RES) {                  // the prefetched registers hold the raw [8 hi][8 lo] bits
+                float r[8];
+                x3_unpack(rv.lo, rv.hi, r);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+                done = true;
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        }
     }
     if (d.relu) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+    }
+    if constexpr (DT == GPP_BF16X3) {
+        if (d.x3_split & GPP_X3_OUT) {
+            x3_store(d.out, obase, n, v);
+            return;
+        }
     }
     if (d.out_f32) {
         float* dst = (float*)d.out + obase + n;
@@ -306,9 +367,12 @@ template <> struct Elem<GPP_BF16X3> {
 
 template <int DT> constexpr bool kF32Storage = (DT == GPP_F32 || DT == GPP_BF16X3);
 
-template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
+// XIN (GPP_BF16X3 only): the input map is pre-split (gpp_conv_desc.x3_split & GPP_X3_IN) -- a compile-time property of the kernel, so
+// that the loop of either form carries no trace of the other (the 256 x 256 tile has no registers to spare for both)
+template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool XIN = false>
 __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const int block_x, const int grid_x)
 {
+    static_assert(!XIN || DT == GPP_BF16X3, "pre-split input maps: GPP_BF16X3");
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
     using frag = typename E::frag;
@@ -460,7 +524,17 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
 #pragma unroll
                 for (int jj = 0; jj < NF / 2; ++jj) {
                     const int n = n0 + wn * (BN / WN) + jj * 32 + (lane >> 4) * 8;
-                    rpre[i][jj] = *(const vec8*)((const scalar*)d.residual + ra_pre[i].rbase + (n < d.C_out ? n : 0));
+                    const int nc = n < d.C_out ? n : 0;
+                    bool raw = false;
+                    if constexpr (DT == GPP_BF16X3) {
+                        if (d.x3_split & GPP_X3_RES) {          // pre-split shortcut map: the two 16-byte halves as they are
+                            const char* p = x3_addr(d.residual, ra_pre[i].rbase, nc);
+                            rpre[i][jj].lo = *(const f32x4*)p;
+                            rpre[i][jj].hi = *(const f32x4*)(p + 64);
+                            raw = true;
+                        }
+                    }
+                    if (!raw) rpre[i][jj] = *(const vec8*)((const scalar*)d.residual + ra_pre[i].rbase + nc);
                 }
             }
         }
@@ -668,10 +742,19 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 // the two cross terms first, the dominant hi * hi term last
                 const unsigned char* sbase = smem + cbuf * STAGE;
                 bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
+                if constexpr (XIN) {
+                    // pre-split activations: the row holds [32 bf16 hi | 32 bf16 lo], exactly as the weight rows do
 #pragma unroll
-                for (int i = 0; i < MF; ++i)
-                    Elem<GPP_BF16X3>::split(*(const f32x4*)(sbase + a_rdx[0] + i * 16 * kRowBytes),
-                                            *(const f32x4*)(sbase + a_rdx[1] + i * 16 * kRowBytes), ah[i], al[i]);
+                    for (int i = 0; i < MF; ++i) {
+                        ah[i] = *(const bf16x8*)(sbase + a_rd[0] + i * 16 * kRowBytes);
+                        al[i] = *(const bf16x8*)(sbase + a_rd[1] + i * 16 * kRowBytes);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+                        Elem<GPP_BF16X3>::split(*(const f32x4*)(sbase + a_rdx[0] + i * 16 * kRowBytes),
+                                                *(const f32x4*)(sbase + a_rdx[1] + i * 16 * kRowBytes), ah[i], al[i]);
+                }
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     bh[j] = *(const bf16x8*)(sbase + b_rd[0] + j * 16 * kRowBytes);
@@ -817,10 +900,10 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     GPP_STAMP_END();
 }
 
-template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
+template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool XIN = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_conv_desc d)
 {
-    conv_igemm_body<DT, BM, BN, WM, WN, STAGES, PIPE>(d, blockIdx.x, gridDim.x);
+    conv_igemm_body<DT, BM, BN, WM, WN, STAGES, PIPE, XIN>(d, blockIdx.x, gridDim.x);
 }
 
 // A layer whose C_out is an odd multiple of 128 (the fused tower inputs: 896 = 3 x 256 + 128) in ONE grid of two tile
@@ -1285,13 +1368,16 @@ struct DeviceOnce {
 };
 
 // One tile configuration: block tile BM x BN, WM x WN wavefronts, STAGES-deep LDS ring.
-template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
+template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool XIN = false>
 int launch(gpp_conv_desc& d, hipStream_t st)
 {
+    if constexpr (DT == GPP_BF16X3 && !XIN) {
+        if (d.x3_split & GPP_X3_IN) return launch<DT, BM, BN, WM, WN, STAGES, PIPE, true>(d, st);      // the pre-split-input form of this tile
+    }
     constexpr int lds = STAGES * (BM + BN) * kRowBytes;
     constexpr int CK = kRowBytes / Elem<DT>::ESZ;
     static DeviceOnce once;
-    auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES, PIPE>;
+    auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES, PIPE, XIN>;
     int rc = once.configure(kernel, lds);
     if (rc != GPP_OK) return rc;
     const int tiles = prepare<BM, BN>(d);

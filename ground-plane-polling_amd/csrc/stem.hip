@@ -438,6 +438,27 @@ __global__ __launch_bounds__(256) void relu_kernel(const scalar* __restrict__ in
     }
 }
 
+// ReLU on a pre-split GPP_BF16X3 map: every 128 bytes are [32 bf16 hi | 32 bf16 lo] of 32 channels, value = hi + lo with
+// |lo| <= ulp(hi) / 2, so the sign of the value is the sign of hi: a negative hi clears the pair, everything else stays.
+__global__ __launch_bounds__(256) void relu_x3_kernel(const char* __restrict__ in, int64_t in_bs_bytes, char* __restrict__ out,
+                                                      int64_t out_bs_bytes, int64_t groups)
+{
+    const char* src = in + (int64_t)blockIdx.y * in_bs_bytes;
+    char* dst = out + (int64_t)blockIdx.y * out_bs_bytes;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+        const int64_t off = (g >> 2) * 128 + (g & 3) * 16;       // 8 channels: 16 bytes of hi, their lo 64 bytes further
+        bf16x8 h = *(const bf16x8*)(src + off), l = *(const bf16x8*)(src + off + 64);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool neg = (float)h[c] < 0.0f;
+            h[c] = neg ? (__bf16)0.0f : h[c];
+            l[c] = neg ? (__bf16)0.0f : l[c];
+        }
+        *(bf16x8*)(dst + off) = h;
+        *(bf16x8*)(dst + off + 64) = l;
+    }
+}
+
 inline int result()
 {
     hipError_t e = hipGetLastError();
@@ -582,6 +603,11 @@ extern "C" int gpp_relu_strided(const void* in, int64_t in_bstride, void* out, i
     const int64_t n8 = count / 8;
     const dim3 grid((unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == GPP_BF16X3) {                  // a pre-split map: float32-sized elements, whole 32-channel blocks
+        if (count % 32 != 0 || in_bstride % 32 != 0 || out_bstride % 32 != 0) return GPP_ERR_BAD_ARG;
+        relu_x3_kernel<<<grid, 256, 0, st>>>((const char*)in, in_bstride * 4, (char*)out, out_bstride * 4, count / 8);
+        return result();
+    }
     if (dtype == GPP_BF16)
         relu_kernel<__bf16, bf16x8><<<grid, 256, 0, st>>>((const __bf16*)in, in_bstride, (__bf16*)out, out_bstride, n8);
     else if (dtype == GPP_F16)

@@ -66,7 +66,8 @@ class ConvDesc(ctypes.Structure):
                 ('tile_hint', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('in_bytes', ctypes.c_int32), ('weight_bytes', ctypes.c_int32),
                 ('partial', c_void_p), ('partial_bytes', c_int64), ('split_k', ctypes.c_int32), ('partial_rows', ctypes.c_int32),
-                ('groups', ConvGroup * GPP_MAX_GROUPS)]
+                ('groups', ConvGroup * GPP_MAX_GROUPS),
+                ('x3_split', ctypes.c_int32), ('reserved2', ctypes.c_int32)]
 
 
 def _declare(lib):

@@ -43,11 +43,16 @@ class FMap(object):
     """ A feature map living inside a torch buffer: pixel (b, y, x) starts at element
     off + b*bstride + (y*W + x)*pitch and has C contiguous channels. """
 
-    def __init__(self, buf, B, H, W, C, off=0, bstride=None, pitch=None):
+    def __init__(self, buf, B, H, W, C, off=0, bstride=None, pitch=None, split=False):
         self.buf, self.B, self.H, self.W, self.C = buf, int(B), int(H), int(W), int(C)
         self.off = int(off)
         self.pitch = int(C if pitch is None else pitch)
         self.bstride = int(self.H * self.W * self.pitch if bstride is None else bstride)
+        # dtype='bf16x3' only: a PRE-SPLIT map -- every 32 channels of a pixel (128 bytes of the float32-typed buffer) hold
+        # [32 bf16 hi | 32 bf16 lo], hi = bf16(x), lo = bf16(x - hi), instead of 32 float32 (gpp_conv_desc.x3_split)
+        self.split = bool(split)
+        if self.split:
+            assert self.C % 32 == 0 and self.pitch % 32 == 0 and self.off % 32 == 0 and self.bstride % 32 == 0
 
     @classmethod
     def empty(cls, B, H, W, C, dtype, device):
@@ -55,10 +60,30 @@ class FMap(object):
         return cls(torch.empty((B, H, W, C), dtype=dtype, device=device), B, H, W, C)
 
     def dense(self):
-        """ (B, H, W, C) torch view of the map (needs pitch*W*H <= bstride). """
+        """ (B, H, W, C) torch view of the map (needs pitch*W*H <= bstride); raw storage -- for a pre-split map use read / write. """
         import torch
         return torch.as_strided(self.buf.view(-1), (self.B, self.H, self.W, self.C),
                                 (self.bstride, self.W * self.pitch, self.pitch, 1), self.off)
+
+    def read(self):
+        """ (B, H, W, C) tensor of the VALUES of the map (a copy for pre-split maps: hi + lo in float32) """
+        import torch
+        if not self.split:
+            return self.dense()
+        raw = self.dense().contiguous().view(torch.bfloat16).reshape(self.B, self.H, self.W, self.C // 32, 2, 32).float()
+        return (raw[..., 0, :] + raw[..., 1, :]).reshape(self.B, self.H, self.W, self.C)
+
+    def write(self, values):
+        """ store a (B, H, W, C) tensor of values into the map (pre-split maps: split here, as the kernels' epilogue does) """
+        import torch
+        if not self.split:
+            self.dense().copy_(values.to(self.buf.dtype))
+            return
+        v = values.to(device=self.buf.device, dtype=torch.float32).reshape(self.B, self.H, self.W, self.C // 32, 32)
+        hi = v.to(torch.bfloat16)
+        lo = (v - hi.float()).to(torch.bfloat16)
+        both = torch.stack([hi, lo], dim=4).reshape(self.B, self.H, self.W, 2 * self.C)            # [.., chunk, (hi | lo), 32]
+        self.dense().copy_(both.contiguous().view(torch.float32).reshape(self.B, self.H, self.W, self.C))
 
 
 def pack_weight(kernel_hwio, dtype, device):
@@ -141,6 +166,9 @@ def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=
         d.partial = workspace.data_ptr()
         d.partial_bytes = workspace.numel() * workspace.element_size()
     d.split_k = int(split_k)
+    d.x3_split = (1 if inputs[0].split else 0) | (2 if outputs[0].split else 0) | (4 if (residuals and residuals[0].split) else 0)
+    assert d.x3_split == 0 or dtype == 'bf16x3'
+    assert all(f.split == inputs[0].split for f in inputs) and all(f.split == outputs[0].split for f in outputs)
     assert 1 <= len(inputs) <= hip.GPP_MAX_GROUPS and len(outputs) == len(inputs)
     assert int(weight.shape[1]) == KH * KW * C_in
     for g, (fi, fo) in enumerate(zip(inputs, outputs)):

@@ -342,29 +342,41 @@ class RetinaNet3D(object):
         lvl_off = [sum(pix[:i]) for i in range(5)]
         plan.n_anchors = total * anchor_utils.NUM_BASE_ANCHORS
 
+        # dtype='bf16x3': the maps between the FPN / head layers -- 80 % of the FLOPs, all of them matrix-pipe bound -- are stored
+        # PRE-SPLIT ([32 bf16 hi | 32 bf16 lo] per 32 channels, gpp_conv_desc.x3_split): written that way by the producing layer's
+        # epilogue, read by the consumers without the per-fragment split on the vector ALU (GPP_X3_SPLIT=0: plain float32 maps).
+        # The backbone maps stay float32: its layers are bound by their tile fill, not by the matrix pipe.
+        x3s = self.dtype == 'bf16x3' and os.environ.get('GPP_X3_SPLIT', '1') != '0'
+
         def pyramid(c, dtype=None):
             buf = torch.empty((B, total, c), dtype=dtype or dt, device=dev)
             plan.keep.append(buf)
-            return buf, [C.FMap(buf, B, shapes[i][0], shapes[i][1], c, off=lvl_off[i] * c, bstride=total * c) for i in range(5)]
+            sp = x3s and dtype is None
+            return buf, [C.FMap(buf, B, shapes[i][0], shapes[i][1], c, off=lvl_off[i] * c, bstride=total * c, split=sp) for i in range(5)]
+
+        def smap(h, w, c):
+            f = fmap(h, w, c)
+            f.split = x3s
+            return f
 
         pyr, P = pyramid(512)
-        T5 = fmap(C5.H, C5.W, 512)
+        T5 = smap(C5.H, C5.W, 512)
         # P5 and the P6 -> ReLU -> P7 chain are small launches (a few dozen tiles) independent of the C4 / C3 chain:
         # with GPP_HEAD_LANES=1 they run on the side streams underneath the big P4 / P3 launches
         l_p5, l_p6 = (1, 2) if head_lanes else (0, 0)
         self._conv(plan, 'C5_reduced', [C5], [T5], 1)
         self._conv(plan, 'P5', [T5], [P[2]], 3, pad=(1, 1), lane=l_p5)
         self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]), lane=l_p6)
-        R6 = fmap(shapes[3][0], shapes[3][1], 512)
+        R6 = smap(shapes[3][0], shapes[3][1], 512)
         plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * self.esz, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
-                                   pix[3] * 512, C.gpp_storage_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
+                                   pix[3] * 512, hip.GPP_BF16X3 if x3s else C.gpp_storage_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
         plan.relu_io = (P[3], R6)
         self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
                    pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]), lane=l_p6)
-        T4 = fmap(C4.H, C4.W, 512)
+        T4 = smap(C4.H, C4.W, 512)
         self._conv(plan, 'C4_reduced', [C4], [T4], 1, residuals=[T5])          # + UpsampleLike(P5, C4), fused
         self._conv(plan, 'P4', [T4], [P[1]], 3, pad=(1, 1))
-        T3 = fmap(C3.H, C3.W, 512)
+        T3 = smap(C3.H, C3.W, 512)
         self._conv(plan, 'C3_reduced', [C3], [T3], 1, residuals=[T4])          # + UpsampleLike(P4, C3), fused
         self._conv(plan, 'P3', [T3], [P[0]], 3, pad=(1, 1))
 
@@ -375,7 +387,7 @@ class RetinaNet3D(object):
         # tensor; layers 1..3 read their channel slice of it (in_pitch > C_in)
         wide, wide_maps = pyramid(896)
         def slice_of(maps, c0, c):
-            return [C.FMap(m.buf, B, m.H, m.W, c, off=m.off + c0, bstride=m.bstride, pitch=m.pitch) for m in maps]
+            return [C.FMap(m.buf, B, m.H, m.W, c, off=m.off + c0, bstride=m.bstride, pitch=m.pitch, split=m.split) for m in maps]
 
         # (measured and rejected: the half-empty fourth 256-column tile of this 896-wide layer as its own 128-column launch
         # on a side stream -- the two launches do not pack into each other's partial rounds, no gain)

@@ -157,7 +157,18 @@ typedef struct gpp_conv_desc {
     int32_t split_k;                /* 0 = gpp_conv2d_split_rule (a function of the layer alone), 1 = never, k > 1 = exactly k */
     int32_t partial_rows;           /* filled in by the library */
     gpp_conv_group groups[GPP_MAX_GROUPS];
+    int32_t x3_split;               /* GPP_BF16X3 only (0 otherwise): which of the float32-sized maps hold PRE-SPLIT values, bits
+                                       GPP_X3_IN | GPP_X3_OUT | GPP_X3_RES.  A pre-split map stores every 32 channels of a pixel
+                                       (128 bytes) as [32 bf16 hi | 32 bf16 lo], hi = bf16(x), lo = bf16(x - hi) -- the layout the
+                                       packed weights already have -- instead of 32 float32: the matrix loop then takes its
+                                       operands straight from LDS, without the per-fragment split on the vector ALU that shares
+                                       issue slots with the matrix pipe.  Needs pitches and offsets that are multiples of 32
+                                       channels; an output map can be pre-split only when out_f32 == 0 and C_out % 32 == 0 */
+    int32_t reserved2;              /* must be 0 */
 } gpp_conv_desc;
+#define GPP_X3_IN 1
+#define GPP_X3_OUT 2
+#define GPP_X3_RES 4
 
 int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream);
 
@@ -217,6 +228,8 @@ int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B, int H, in
  * gpp_stem_conv7x7_bn_relu_mfma followed by gpp_maxpool3x3s2_same (the max is taken over the rounded conv values). */
 int gpp_stem_pool_fused_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
                              int dtype, int B, int H, int W, void* stream);
+/* dtype GPP_BF16X3 = a pre-split map (gpp_conv_desc.x3_split): ReLU on the [hi | lo] pairs (count in float32-sized elements, a
+   multiple of 32) */
 int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream);
 /* batched form: image b reads `count` elements at in + b*in_bstride, writes out + b*out_bstride */
 int gpp_relu_strided(const void* in, int64_t in_bstride, void* out, int64_t out_bstride, int dtype, int B,

@@ -268,3 +268,95 @@ def test_f32_stem_pool_relu():
     y = torch.empty_like(x)
     hip.check(hip.lib().gpp_relu(hip.ptr(x), hip.ptr(y), hip.GPP_F32, x.numel(), hip.stream_ptr()), 'relu')
     assert torch.equal(y, torch.relu(x))
+
+
+def _x3_round(t):
+    """ what a pre-split map can hold: hi + lo with hi = bf16(x), lo = bf16(x - hi) (about 16 significant bits) """
+    hi = t.to(torch.bfloat16).float()
+    return hi + (t - hi).to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize('flags', [1, 2, 4, 3, 7])
+@pytest.mark.parametrize('tile', [0, 96128, 192128, 128256])
+@pytest.mark.parametrize('case', ['3x3_wide', '1x1_res_up_nonint', 'bottleneck_2c', '3x3_s2_tfsame', 'deepK'])
+def test_bf16x3_pre_split_maps(case, tile, flags):
+    """ gpp_conv_desc.x3_split: input / output / shortcut maps stored as [32 bf16 hi | 32 bf16 lo] per 32 channels.  The matrix
+    loop then reads its operands as they are; the epilogue splits what it stores and re-joins the shortcut it reads.  Against the
+    float64 reference on the values the maps actually hold, with the bar of the float32-storage form, plus the 2^-17 of a split
+    output; split-K (deepK), every combination of the three flags, plain and 8-wavefront tiles. """
+    name, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, _ = [c for c in CASES if c[0] == case][0]
+    if (flags & 4) and resmode is None:
+        pytest.skip('no shortcut in this layer')
+    if Cin % 32 or ((flags & 6) and Cout % 32):
+        pytest.skip('pre-split maps hold whole 32-channel blocks')
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + flags)
+    dev = torch.device('cuda')
+    x = torch.randn((B, H, W, Cin), generator=g)
+    k = torch.randn((K, K, Cin, Cout), generator=g) * (2.0 / (K * K * Cin)) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    if pad is None:
+        oh, pt = C.same_pad(H, K, stride)
+        ow, pl = C.same_pad(W, K, stride)
+    else:
+        pt, pl = pad
+        oh, ow = out_hw if out_hw else (H, W)
+    res = None
+    if resmode == 'same':
+        res = torch.randn((B, oh, ow, Cout), generator=g)
+    elif resmode is not None:
+        res = torch.randn((B, resmode[0], resmode[1], Cout), generator=g)
+    x_held = _x3_round(x) if flags & 1 else x
+    res_held = None if res is None else (_x3_round(res) if flags & 4 else res)
+    ref = reference64(x_held, k, bias, stride, pt, pl, oh, ow, relu, res_held)
+    xin = C.FMap.empty(B, H, W, Cin, torch.float32, dev)
+    xin.split = bool(flags & 1)
+    xin.write(x)
+    out = C.FMap.empty(B, oh, ow, Cout, torch.float32, dev)
+    out.split = bool(flags & 2)
+    out.buf.fill_(float('nan'))
+    rmap = None
+    if res is not None:
+        rm = C.FMap.empty(B, res.shape[1], res.shape[2], Cout, torch.float32, dev)
+        rm.split = bool(flags & 4)
+        rm.write(res)
+        rmap = [rm]
+    w = C.pack_weight(k.numpy(), 'bf16x3', dev)
+    ws = torch.empty((32 << 20,), dtype=torch.uint8, device=dev)
+    split_k = 3 if case == 'deepK' else 1
+    d = C.conv_desc([xin], [out], w, bias.to(dev), K, K, Cin, Cout, stride=stride, pad=(pt, pl), relu=relu, residuals=rmap,
+                    dtype='bf16x3', tile_hint=tile, workspace=ws, split_k=split_k)
+    assert d.x3_split == (flags if res is not None else flags & 3)
+    bn = tile % 1000 if tile else 64
+    if -(-d.C_out // bn) * bn > d.weight_rows:
+        pytest.skip('tile grid would read past the packed weight rows')
+    C.run_conv(d)
+    got = out.read().double().cpu()
+    assert torch.isfinite(got).all()
+    rms = float(ref.pow(2).mean().sqrt())
+    err = (got - ref).abs()
+    assert bool((err <= 1.2e-4 * ref.abs() + 1e-4 * rms).all()), 'max err {} (rms {})'.format(err.max().item(), rms)
+    assert float(err.pow(2).mean().sqrt()) < 2.5e-5 * rms + 1e-7
+
+
+def test_bf16x3_pre_split_flags_are_validated():
+    make, _, _, _, _ = _layer([c for c in CASES if c[0] == '3x3_wide'][0], dtype='f32')
+    d = make(0)
+    d.x3_split = 1                                             # only GPP_BF16X3 knows the layout
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -1
+    make, _, _, _, _ = _layer([c for c in CASES if c[0] == 'head_out144_f32'][0], dtype='bf16x3')
+    d = make(0)
+    d.x3_split = 2                                             # 144 output channels: not whole 32-channel blocks
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -4
+    d.x3_split = 8
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -1
+
+
+def test_relu_on_a_pre_split_map():
+    dev = torch.device('cuda')
+    x = torch.randn((2, 5, 7, 64))
+    src = C.FMap.empty(2, 5, 7, 64, torch.float32, dev)
+    dst = C.FMap.empty(2, 5, 7, 64, torch.float32, dev)
+    src.split = dst.split = True
+    src.write(x)
+    hip.check(hip.lib().gpp_relu(hip.ptr(src.buf), hip.ptr(dst.buf), hip.GPP_BF16X3, x.numel(), hip.stream_ptr()))
+    assert torch.equal(dst.read().cpu(), torch.relu(_x3_round(x)))

@@ -412,10 +412,10 @@ def check_every_layer(backbone, dtype, fuse_next, batch, h, w, monkeypatch):
     def feed(fm):
         arr = produced[key(fm)][..., :fm.C]
         assert arr.shape == (fm.B, fm.H, fm.W, fm.C), (arr.shape, (fm.B, fm.H, fm.W, fm.C))
-        fm.dense().copy_(torch.as_tensor(np.ascontiguousarray(arr)).to(fm.buf.dtype))
+        fm.write(torch.as_tensor(np.ascontiguousarray(arr)))          # (a pre-split bf16x3 map splits the values here)
 
     def compare(name, fm, want, slack=1e-4):
-        got = fm.dense().float().cpu().numpy()
+        got = fm.read().float().cpu().numpy()
         assert got.shape == want.shape, (name, got.shape, want.shape)
         rms = float(np.sqrt((want.astype(np.float64) ** 2).mean())) + 1e-30
         err = np.abs(got - want)
@@ -446,7 +446,8 @@ def check_every_layer(backbone, dtype, fuse_next, batch, h, w, monkeypatch):
             src, dst = plan.relu_io
             feed(src)
             model50.run_op(plan, index)
-            assert (dst.dense().float().cpu().numpy() == tr[('C6_relu', 0)]).all()
+            got_relu = dst.read().float().cpu().numpy()
+            assert (got_relu == tr[('C6_relu', 0)]).all() if not dst.split else np.allclose(got_relu, tr[('C6_relu', 0)], rtol=2e-5, atol=0)
             register(dst, tr[('C6_relu', 0)])
         elif kind in (OP_CONV, OP_TAIL, OP_TAIL_NEXT):
             inputs, outputs, residuals = plan.io[name]
