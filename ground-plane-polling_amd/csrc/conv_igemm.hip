@@ -190,7 +190,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
 {
     if (!desc || iters < 1) return GPP_ERR_BAD_ARG;
     static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
-                                 1128128, 1192128, 1128256, 1192256, 256256,
+                                 1128128, 1192128, 1128256, 1192256, 256256, 1256256,
                                  128160, 192160, 1192160, 2256256,
                                  128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
     // (the loader-wavefront form, tile codes 3064128 / 3096128 / 3128128 / 3064256 of conv_ring_impl.h, is not a candidate:
@@ -231,7 +231,11 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         if (tile >= 3000000 && f32_storage(desc->dtype)) continue;
         if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
         if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) continue;
-        if (tile > 1000000 && tile < 3000000 && (nk < 4 || f32_storage(desc->dtype))) continue;   // the pipelined loop needs a few K-steps to pay; 16-bit only
+        // the pipelined loops need a few K-steps to pay; 16-bit types, and GPP_BF16X3 on a pre-split input map
+        const bool x3_pipe = desc->dtype == GPP_BF16X3 && (desc->x3_split & GPP_X3_IN);
+        if (tile > 1000000 && tile < 3000000 && (nk < 4 || (f32_storage(desc->dtype) && !x3_pipe))) continue;
+        if (tile == 1256256 && !x3_pipe) continue;
+        if (x3_pipe && (tile == 1192160 || tile == 2256256)) continue;
         if (bn == 256 && desc->dtype == GPP_F32) continue;
         if ((tile == 128256 || tile == 192256) && desc->dtype != GPP_BF16X3) continue;
         if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding

@@ -635,6 +635,81 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             set_tap(kh, kw);
             ++issued;
         };
+        if constexpr (DT == GPP_BF16X3) {
+            // ---- pre-split bf16x3 (XIN): a K-step is 32 channels = one k-slice, three matrix products per accumulator, three phases:
+            //   phase A:  MFMA(hi * wlo)  ||  LDS reads of whi (this stage)
+            //   phase B:  MFMA(hi * whi)  ||  LDS reads of lo  (this stage)
+            //   wait stage k+1 landed, lgkmcnt(0), s_barrier                 (everyone is done reading buffer k&1)
+            //   phase C:  MFMA(lo * whi)  ||  LDS-DMA of stage k+2 into buffer k&1  ||  LDS reads of hi, wlo of stage k+1
+            // hi is live in A-B, lo in C, whi in B-C, wlo in A: every fragment set is reloaded while the phase that runs does not use
+            // it, so the four sets take 96 registers (as in the 16-bit loop) and the body needs no second copy.  One barrier per
+            // 3 MF NF MFMAs; the DMA of stage k+2 has two phases to land.
+            static_assert(XIN, "the pipelined bf16x3 loop reads pre-split activation rows");
+            bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
+#pragma unroll
+            for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 0, in_rsrc, w_rsrc, cc * kRowBytes, ks0 * kRowBytes);
+            advance_tap();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                const bool live = issued < nk;
+                const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
+#pragma unroll
+                for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 1, ra, rw, cc * kRowBytes, (ks0 + issued) * kRowBytes);
+                if (live) advance_tap();
+            }
+#pragma unroll
+            for (int i = 0; i < MF; ++i) ah[i] = *(const bf16x8*)(smem + a_rd[0] + i * 16 * kRowBytes);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bl[j] = *(const bf16x8*)(smem + b_rd[1] + j * 16 * kRowBytes);
+            if (NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+            for (int ks = 0; ks < nk; ++ks) {
+                const int cur = ks & 1;
+                const unsigned char* scur = smem + cur * STAGE;
+                const unsigned char* snxt = smem + (cur ^ 1) * STAGE;
+                const bool live = issued < nk;
+                const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
+                const int so_a = __builtin_amdgcn_readfirstlane(cc * kRowBytes), so_w = __builtin_amdgcn_readfirstlane((ks0 + issued) * kRowBytes);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- phase A: hi * wlo, fetch whi
+#pragma unroll
+                for (int g = 0; g < MF; ++g) {
+#pragma unroll
+                    for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) bh[j] = *(const bf16x8*)(scur + b_rd[0] + j * 16 * kRowBytes);
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[g], acc[g][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- phase B: hi * whi, fetch lo
+#pragma unroll
+                for (int g = 0; g < MF; ++g) {
+                    al[g] = *(const bf16x8*)(scur + a_rd[1] + g * 16 * kRowBytes);
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[g], acc[g][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- phase C: lo * whi, stage k+2 goes out, fetch hi and wlo of stage k+1
+#pragma unroll
+                for (int g = 0; g < MF; ++g) {
+#pragma unroll
+                    for (int idx = g * PER_STAGE / MF; idx < (g + 1) * PER_STAGE / MF; ++idx) issue_one(idx, cur, ra, rw, so_a, so_w);
+                    ah[g] = *(const bf16x8*)(snxt + a_rd[0] + g * 16 * kRowBytes);
+#pragma unroll
+                    for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) bl[j] = *(const bf16x8*)(snxt + b_rd[1] + j * 16 * kRowBytes);
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[g], acc[g][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (live) advance_tap();
+            }
+            if (NW == 8) __builtin_amdgcn_s_setprio(0);
+        } else {
         frag a0[MF], b0[NF], a1[MF], b1[NF];
         // prologue: stage 0 -> buffer 0, wait, stage 1 -> buffer 1, fragments kk=0 of step 0
 #pragma unroll
@@ -700,6 +775,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             if (live) advance_tap();         // a_voff for the next issue changes only after this step's DMA is out
         }
         if (NW == 8) __builtin_amdgcn_s_setprio(0);
+        }
     } else {
 #pragma unroll
     for (int p = 0; p < PF; ++p)
@@ -738,8 +814,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
 #endif
         {
             if constexpr (DT == GPP_BF16X3) {
-                // one 32-channel K-step = one k-slice of v_mfma_f32_16x16x32_bf16, three matrix products per accumulator:
-                // the two cross terms first, the dominant hi * hi term last
+                // one 32-channel K-step = one k-slice of v_mfma_f32_16x16x32_bf16, three matrix products per accumulator
                 const unsigned char* sbase = smem + cbuf * STAGE;
                 bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
                 if constexpr (XIN) {
@@ -760,17 +835,19 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                     bh[j] = *(const bf16x8*)(sbase + b_rd[0] + j * 16 * kRowBytes);
                     bl[j] = *(const bf16x8*)(sbase + b_rd[1] + j * 16 * kRowBytes);
                 }
+                // per accumulator and K-step: hi * wlo, hi * whi, lo * whi -- the order of the software-pipelined form below (its
+                // three phases), so that every bf16x3 tile sums an output element in the same order
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
                     for (int j = 0; j < NF; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
                     }
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -1490,12 +1567,23 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                 // GPP_BF16X3 spends 3 MFMAs per fragment pair: with 4-wavefront tiles its LDS traffic equals its matrix time;
                 // the 8-wavefront 256-column tiles (plain two-buffer loop) halve the LDS bytes per MFMA
                 if constexpr (DT == GPP_BF16X3) {
+                    if (d.x3_split & GPP_X3_IN) {
+                        // the software-pipelined three-phase loop: pre-split input maps only (1000000 + tile, as for the 16-bit types)
+                        switch (d.tile_hint) {
+                            case 1256256: return launch<DT, 256, 256, 2, 4, 2, true, true>(d, st);
+                            case 1192256: return launch<DT, 192, 256, 2, 4, 2, true, true>(d, st);
+                            case 1128256: return launch<DT, 128, 256, 2, 4, 2, true, true>(d, st);
+                            case 1192128: return launch<DT, 192, 128, 2, 2, 2, true, true>(d, st);
+                            case 1128128: return launch<DT, 128, 128, 2, 2, 2, true, true>(d, st);
+                            default: break;
+                        }
+                    }
                     if (d.tile_hint == 256256) return launch<DT, 256, 256, 2, 4, 2, false>(d, st);
                     if (d.tile_hint == 192256) return launch<DT, 192, 256, 2, 4, 2, false>(d, st);
                     if (d.tile_hint == 128256) return launch<DT, 128, 256, 2, 4, 2, false>(d, st);
                 }
                 switch (d.tile_hint) {
-                    case 256: case 1128128: case 1192128: case 1128256: case 1192256: case 1192160: case 2256256: case 512: case 256256:
+                    case 256: case 1128128: case 1192128: case 1128256: case 1192256: case 1192160: case 2256256: case 512: case 256256: case 1256256:
                     case 192256: case 128256:
                         return GPP_ERR_UNSUPPORTED;
                     default: return GPP_ERR_BAD_ARG;

@@ -277,7 +277,7 @@ def _x3_round(t):
 
 
 @pytest.mark.parametrize('flags', [1, 2, 4, 3, 7])
-@pytest.mark.parametrize('tile', [0, 96128, 192128, 128256])
+@pytest.mark.parametrize('tile', [0, 96128, 192128, 128256, 1256256, 1192128])
 @pytest.mark.parametrize('case', ['3x3_wide', '1x1_res_up_nonint', 'bottleneck_2c', '3x3_s2_tfsame', 'deepK'])
 def test_bf16x3_pre_split_maps(case, tile, flags):
     """ gpp_conv_desc.x3_split: input / output / shortcut maps stored as [32 bf16 hi | 32 bf16 lo] per 32 channels.  The matrix
@@ -329,6 +329,9 @@ def test_bf16x3_pre_split_maps(case, tile, flags):
     bn = tile % 1000 if tile else 64
     if -(-d.C_out // bn) * bn > d.weight_rows:
         pytest.skip('tile grid would read past the packed weight rows')
+    if tile > 1000000 and not (flags & 1):
+        assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -4      # the pipelined loop reads pre-split rows
+        return
     C.run_conv(d)
     got = out.read().double().cpu()
     assert torch.isfinite(got).all()
@@ -360,3 +363,54 @@ def test_relu_on_a_pre_split_map():
     src.write(x)
     hip.check(hip.lib().gpp_relu(hip.ptr(src.buf), hip.ptr(dst.buf), hip.GPP_BF16X3, x.numel(), hip.stream_ptr()))
     assert torch.equal(dst.read().cpu(), torch.relu(_x3_round(x)))
+
+
+X3_PIPE_TILES = [1128128, 1192128, 1128256, 1192256, 1256256]
+
+
+@pytest.mark.parametrize('case', ['3x3_wide', 'bottleneck_2c', '3x3_s2_tfsame', 'deepK', '1x1'])
+def test_every_bf16x3_tile_on_pre_split_maps_gives_identical_results(case):
+    """ plain and software-pipelined (three-phase) tiles sum an output element in the same order: hi * wlo, hi * whi, lo * whi per
+    K-step -- identical bits, with and without split-K """
+    name, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, _ = [c for c in CASES if c[0] == case][0]
+    g = torch.Generator().manual_seed(len(name))
+    dev = torch.device('cuda')
+    x = torch.randn((B, H, W, Cin), generator=g)
+    k = torch.randn((K, K, Cin, Cout), generator=g) * (2.0 / (K * K * Cin)) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    if pad is None:
+        oh, pt = C.same_pad(H, K, stride)
+        ow, pl = C.same_pad(W, K, stride)
+    else:
+        pt, pl = pad
+        oh, ow = out_hw if out_hw else (H, W)
+    xin = C.FMap.empty(B, H, W, Cin, torch.float32, dev)
+    xin.split = True
+    xin.write(x)
+    out = C.FMap.empty(B, oh, ow, Cout, torch.float32, dev)
+    out.split = Cout % 32 == 0
+    rmap = None
+    if resmode == 'same':
+        rm = C.FMap.empty(B, oh, ow, Cout, torch.float32, dev)
+        rm.split = True
+        rm.write(torch.randn((B, oh, ow, Cout), generator=g))
+        rmap = [rm]
+    w = C.pack_weight(k.numpy(), 'bf16x3', dev)
+    ws = torch.empty((32 << 20,), dtype=torch.uint8, device=dev)
+    nk = K * K * (Cin // 32)
+    for split_k in (1, 3):
+        if nk < 4 * split_k:
+            continue
+        base = None
+        for tile in X3_TILES + X3_PIPE_TILES:
+            d = C.conv_desc([xin], [out], w, bias.to(dev), K, K, Cin, Cout, stride=stride, pad=(pt, pl), relu=relu, residuals=rmap,
+                            dtype='bf16x3', tile_hint=tile, workspace=ws, split_k=split_k)
+            if -(-d.C_out // (tile % 1000)) * (tile % 1000) > d.weight_rows:
+                continue
+            out.buf.fill_(float('nan'))
+            C.run_conv(d)
+            got = out.buf.clone()
+            assert torch.isfinite(out.read()).all()
+            if base is None:
+                base = got
+            assert torch.equal(got.view(torch.int32), base.view(torch.int32)), (tile, split_k)
