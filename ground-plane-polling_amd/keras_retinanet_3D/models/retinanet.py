@@ -242,6 +242,15 @@ class RetinaNet3D(object):
             plan.keep.append(f.buf)
             return f
 
+        # dtype='bf16x3': maps written and read by convolutions only are stored PRE-SPLIT ([32 bf16 hi | 32 bf16 lo] per 32 channels,
+        # gpp_conv_desc.x3_split): GPP_X3_SPLIT=2 (default) every such map, 1 = only the maps between the FPN / head layers, 0 = none
+        x3_level = int(os.environ.get('GPP_X3_SPLIT', '2')) if self.dtype == 'bf16x3' else 0
+
+        def bmap(h, w, c):
+            f = fmap(h, w, c)
+            f.split = x3_level >= 2
+            return f
+
         # ---- inputs
         plan.images = torch.empty((B, H, Wd, 3), dtype=torch.float32, device=dev)
         plan.P_inv = torch.empty((B, 4, 3), dtype=torch.float32, device=dev)
@@ -286,7 +295,7 @@ class RetinaNet3D(object):
         fuse_next = os.environ.get('GPP_FUSE_NEXT', '0') != '0'
 
         def sub(fm, c0, nb):
-            return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch)
+            return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch, split=fm.split)
 
         feats = []
         for stage, n_blocks in enumerate(W.BLOCKS[self.backbone_name]):
@@ -298,8 +307,8 @@ class RetinaNet3D(object):
                 stride = 2 if (block == 0 and stage > 0) else 1
                 ho, wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
                 fused = f in fuse_tail and f in (64, 128)
-                rec = {'nm': nm, 'stride': stride, 'a': fmap(ho, wo, f), 'b': None if fused else fmap(ho, wo, f),
-                       'sc': fmap(ho, wo, 4 * f) if block == 0 else None, 'y': fmap(ho, wo, 4 * f)}
+                rec = {'nm': nm, 'stride': stride, 'a': bmap(ho, wo, f), 'b': None if fused else bmap(ho, wo, f),
+                       'sc': bmap(ho, wo, 4 * f) if block == 0 else None, 'y': bmap(ho, wo, 4 * f)}
                 blocks.append(rec)
                 x = rec['y']
             chunk = max(1, min(B, int(env_chunks.split(',')[stage]))) if env_chunks else B
@@ -346,7 +355,7 @@ class RetinaNet3D(object):
         # PRE-SPLIT ([32 bf16 hi | 32 bf16 lo] per 32 channels, gpp_conv_desc.x3_split): written that way by the producing layer's
         # epilogue, read by the consumers without the per-fragment split on the vector ALU (GPP_X3_SPLIT=0: plain float32 maps).
         # The backbone maps stay float32: its layers are bound by their tile fill, not by the matrix pipe.
-        x3s = self.dtype == 'bf16x3' and os.environ.get('GPP_X3_SPLIT', '1') != '0'
+        x3s = x3_level >= 1
 
         def pyramid(c, dtype=None):
             buf = torch.empty((B, total, c), dtype=dtype or dt, device=dev)
