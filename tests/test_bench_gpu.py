@@ -55,3 +55,19 @@ def test_bench_at_reference_precision():
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
     assert rec['dtype'] == 'f32' and rec['roofline']['peak'] == 157.3 and 0.3 < rec['roofline']['frac'] < 1.0
     assert rec['value'] > 20 and rec['config']['parity_ledger'] is None and rec['roofline']['launches_timed'] == 3
+
+
+@pytest.mark.gpu
+def test_bench_stdout_is_one_json_line_on_the_rccl_path():
+    """ the multi-GPU path (RCCL communicator, asynchronous all_gather of the packed detections), forced onto the one GPU of the
+    test box: RCCL prints a version banner on stdout when its first communicator comes up -- bench.py keeps its stdout to the
+    one JSON line the driver parses """
+    env = dict(os.environ, GPP_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29641')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1', '--no-cpu-baseline',
+                          '--no-f32-leg', '--no-host-fed'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                         timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[:500]
+    rec = json.loads(lines[0])
+    assert rec['config']['rccl_world_size'] == 1 and rec['config']['gathered_images_per_step'] == 8 and rec['n_gpus'] == 1
