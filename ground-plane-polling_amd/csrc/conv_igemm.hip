@@ -235,7 +235,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         const bool x3_pipe = desc->dtype == GPP_BF16X3 && (desc->x3_split & GPP_X3_IN);
         if (tile > 1000000 && tile < 3000000 && (nk < 4 || (f32_storage(desc->dtype) && !x3_pipe))) continue;
         if (tile == 1256256 && !x3_pipe) continue;
-        if (x3_pipe && (tile == 1192160 || tile == 2256256)) continue;
+        if (x3_pipe && tile == 1192160) continue;
         if (bn == 256 && desc->dtype == GPP_F32) continue;
         if ((tile == 128256 || tile == 192256) && desc->dtype != GPP_BF16X3) continue;
         if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding

@@ -989,14 +989,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const gpp_c
 // same layer with its weight / bias / output pointers moved to that column block).  Every workgroup does the same amount
 // of matrix work, none of it on padding, and the hardware hands the second range out behind the first, into the CUs its
 // last partial round leaves idle: 1253 workgroups = 5 rounds instead of 1432 = 6 for the 896-column layer.
-template <int DT>
+template <int DT, bool XIN = false>
 __global__ __launch_bounds__(512, 2) void conv_igemm_dual_kernel(const gpp_conv_desc d0, const gpp_conv_desc d1, const int n0,
                                                                  const int split0, const int n1)
 {
     if ((int)blockIdx.x < split0) {
-        if ((int)blockIdx.x < n0) conv_igemm_body<DT, 256, 256, 2, 4, 2, true>(d0, blockIdx.x, n0);
+        if ((int)blockIdx.x < n0) conv_igemm_body<DT, 256, 256, 2, 4, 2, true, XIN>(d0, blockIdx.x, n0);
     } else {
-        conv_igemm_body<DT, 512, 128, 4, 2, 2, true>(d1, (int)blockIdx.x - split0, n1);
+        conv_igemm_body<DT, 512, 128, 4, 2, 2, true, XIN>(d1, (int)blockIdx.x - split0, n1);
     }
 }
 
@@ -1489,17 +1489,21 @@ int launch(gpp_conv_desc& d, hipStream_t st)
 template <int DT>
 int launch_dual(const gpp_conv_desc& d, hipStream_t st)
 {
-    if (d.C_out < 384 || d.C_out % 256 != 128 || d.KH * d.KW * (d.C_in / 64) < 2 || d.split_k > 1) return GPP_ERR_UNSUPPORTED;
+    // 16-bit types, and GPP_BF16X3 on a pre-split input map (its pipelined three-phase loop)
+    constexpr bool X3 = (DT == GPP_BF16X3);
+    constexpr int ESZ = Elem<DT>::ESZ, CK = kRowBytes / ESZ;
+    if (X3 && !(d.x3_split & GPP_X3_IN)) return GPP_ERR_UNSUPPORTED;
+    if (d.C_out < 384 || d.C_out % 256 != 128 || d.KH * d.KW * (d.C_in / CK) < 2 || d.split_k > 1) return GPP_ERR_UNSUPPORTED;
     constexpr int lds = 2 * (512 + 128) * kRowBytes;          // 160 KB: the larger of the two bodies
     static DeviceOnce once;
-    auto kernel = conv_igemm_dual_kernel<DT>;
+    auto kernel = conv_igemm_dual_kernel<DT, X3>;
     int rc = once.configure(kernel, lds);
     if (rc != GPP_OK) return rc;
     const int head = d.C_out - 128;                           // columns of the 256-wide part: a multiple of 256
     gpp_conv_desc d0 = d, d1 = d;
     d0.C_out = head;
     d1.C_out = 128;
-    d1.weight = (const char*)d.weight + (int64_t)head * d.KH * d.KW * d.C_in * 2;
+    d1.weight = (const char*)d.weight + (int64_t)head * d.KH * d.KW * d.C_in * ESZ;
     d1.weight_rows = d.weight_rows - head;
     if (d.bias) d1.bias = d.bias + head;
     for (int g = 0; g < d.n_groups; ++g) {
@@ -1575,6 +1579,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                             case 1128256: return launch<DT, 128, 256, 2, 4, 2, true, true>(d, st);
                             case 1192128: return launch<DT, 192, 128, 2, 2, 2, true, true>(d, st);
                             case 1128128: return launch<DT, 128, 128, 2, 2, 2, true, true>(d, st);
+                            case 2256256: return launch_dual<DT>(d, st);      // C_out = 256 k + 128: the dual-shape grid
                             default: break;
                         }
                     }

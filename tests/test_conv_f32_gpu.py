@@ -414,3 +414,37 @@ def test_every_bf16x3_tile_on_pre_split_maps_gives_identical_results(case):
             if base is None:
                 base = got
             assert torch.equal(got.view(torch.int32), base.view(torch.int32)), (tile, split_k)
+
+
+@pytest.mark.parametrize('cin,cout,relu', [(128, 384, True), (64, 896, True)])
+def test_bf16x3_dual_shape_grid_on_pre_split_maps(cin, cout, relu):
+    """ tile code 2256256 for GPP_BF16X3 (C_out = 256 k + 128, pre-split input): 256 x 256 tiles + 512 x 128 tiles in one grid, both
+    running the three-phase pipelined loop -- the bits of the plain tile, over several feature maps with ragged row counts """
+    g = torch.Generator().manual_seed(cout)
+    dev = torch.device('cuda')
+    B, shapes = 2, [(21, 29), (11, 15), (6, 8), (3, 4)]
+    total = sum(h * w for h, w in shapes)
+    xbuf = torch.empty((B, total, cin), dtype=torch.float32, device=dev)
+    w = C.pack_weight((torch.randn((3, 3, cin, cout), generator=g) * (2.0 / (9 * cin)) ** 0.5).numpy(), 'bf16x3', dev)
+    b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    ins, off = [], 0
+    for h, wd in shapes:
+        fm = C.FMap(xbuf, B, h, wd, cin, off=off * cin, bstride=total * cin, split=True)
+        fm.write(torch.randn((B, h, wd, cin), generator=g))
+        ins.append(fm)
+        off += h * wd
+    results = []
+    for tile in (128128, 2256256):
+        o = torch.full((B, total, cout), float('nan'), dtype=torch.float32, device=dev)
+        outs, off = [], 0
+        for h, wd in shapes:
+            outs.append(C.FMap(o, B, h, wd, cout, off=off * cout, bstride=total * cout, split=True))
+            off += h * wd
+        C.run_conv(C.conv_desc(ins, outs, w, b, 3, 3, cin, cout, pad=(1, 1), relu=relu, dtype='bf16x3', tile_hint=tile))
+        results.append(o.view(torch.int32).cpu())
+        assert torch.isfinite(torch.cat([fm.read().reshape(-1) for fm in outs])).all()
+    assert torch.equal(results[0], results[1])
+    # float32 input maps: the dual grid (a pipelined form) is refused
+    plain = [C.FMap(xbuf, B, h, wd, cin, off=fm.off, bstride=total * cin) for fm, (h, wd) in zip(ins, shapes)]
+    d = C.conv_desc(plain, outs, w, b, 3, 3, cin, cout, pad=(1, 1), relu=relu, dtype='bf16x3', tile_hint=2256256)
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -4
