@@ -13,13 +13,14 @@
 
 namespace {
 
-inline bool f32_storage(int dtype) { return dtype == GPP_F32 || dtype == GPP_BF16X3; }
+inline bool is_x3(int dtype) { return dtype == GPP_BF16X3 || dtype == GPP_F16X3; }
+inline bool f32_storage(int dtype) { return dtype == GPP_F32 || is_x3(dtype); }
 inline int elem_size(int dtype) { return f32_storage(dtype) ? 4 : 2; }
 
 int validate(const gpp_conv_desc& d)
 {
     if (!d.in || !d.weight || !d.out) return GPP_ERR_BAD_ARG;
-    if (d.dtype != GPP_BF16 && d.dtype != GPP_F16 && d.dtype != GPP_F32 && d.dtype != GPP_BF16X3) return GPP_ERR_UNSUPPORTED;
+    if (d.dtype != GPP_BF16 && d.dtype != GPP_F16 && d.dtype != GPP_F32 && !is_x3(d.dtype)) return GPP_ERR_UNSUPPORTED;
     const int esz = elem_size(d.dtype), ck = 128 / esz, va = 16 / esz;     // channels per K-step, elements per 16 bytes
     if (d.batch <= 0 || d.C_in <= 0 || d.C_out <= 0 || d.KH <= 0 || d.KW <= 0) return GPP_ERR_BAD_ARG;
     if (d.KH > 8 || d.KW > 8) return GPP_ERR_UNSUPPORTED;           // tap validity masks are 8 + 8 bits
@@ -31,7 +32,8 @@ int validate(const gpp_conv_desc& d)
     if (d.reserved != 0) return GPP_ERR_BAD_ARG;                    // diagnostic switches exist in -DGPP_STAMPS builds only
 #endif
     if (d.reserved2 != 0 || (d.x3_split & ~(GPP_X3_IN | GPP_X3_OUT | GPP_X3_RES))) return GPP_ERR_BAD_ARG;
-    if (d.x3_split && d.dtype != GPP_BF16X3) return GPP_ERR_BAD_ARG;
+    if (d.x3_split && !is_x3(d.dtype)) return GPP_ERR_BAD_ARG;
+    if (d.out_scale && d.dtype != GPP_F16X3) return GPP_ERR_BAD_ARG;
     if ((d.x3_split & GPP_X3_OUT) && (d.out_f32 || d.C_out % 32 != 0 || d.out_pitch % 32 != 0)) return GPP_ERR_UNSUPPORTED;
     if ((d.x3_split & GPP_X3_IN) && d.in_pitch % 32 != 0) return GPP_ERR_UNSUPPORTED;
     if ((d.x3_split & GPP_X3_RES) && (!d.residual || d.res_pitch % 32 != 0)) return GPP_ERR_UNSUPPORTED;
@@ -79,11 +81,12 @@ int dispatch_any(gpp_conv_desc& d, hipStream_t st)
         case GPP_BF16: return gpp_conv_dispatch_bf16(d, st);
         case GPP_F16: return gpp_conv_dispatch_f16(d, st);
         case GPP_BF16X3: return gpp_conv_dispatch_bf16x3(d, st);
+        case GPP_F16X3: return gpp_conv_dispatch_f16x3(d, st);
         default: return gpp_conv_dispatch_f32(d, st);
     }
 }
 
-int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const gpp_conv_desc* next1x1, int tile_rows, void* stream)
+int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream)
 {
     if (!conv3x3 || !conv1x1) return GPP_ERR_BAD_ARG;
     gpp_conv_desc d1 = *conv3x3, d2 = *conv1x1;
@@ -101,35 +104,14 @@ int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const
     if (G1.H_in != G1.H_out || G1.W_in != G1.W_out || G2.H_out != G1.H_out || G2.W_out != G1.W_out || G2.H_in != G1.H_out || G2.W_in != G1.W_out)
         return GPP_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    gpp_conv_desc d3;
-    if (next1x1) {
-        // the following block's first layer: 1x1 / stride 1 / 4C -> C on the map this launch writes, bias + ReLU, 16-bit output
-        d3 = *next1x1;
-        rc = validate(d3);
-        if (rc != GPP_OK) return rc;
-        const gpp_conv_group& G3 = d3.groups[0];
-        if (d3.dtype != d2.dtype || d3.n_groups != 1 || d3.batch != d2.batch || d3.residual || d3.out_f32 || d2.out_f32) return GPP_ERR_UNSUPPORTED;
-        if (d3.KH != 1 || d3.KW != 1 || d3.stride != 1 || d3.pad_top != 0 || d3.pad_left != 0) return GPP_ERR_UNSUPPORTED;
-        if (d3.C_in != d2.C_out || d3.C_out != d1.C_in || d3.weight_rows < d3.C_out) return GPP_ERR_UNSUPPORTED;
-        if (d3.in != d2.out || G3.in_off != G2.out_off || G3.in_bstride != G2.out_bstride || d3.in_pitch != d2.out_pitch) return GPP_ERR_BAD_ARG;
-        if (G3.H_in != G2.H_out || G3.W_in != G2.W_out || G3.H_out != G2.H_out || G3.W_out != G2.W_out) return GPP_ERR_BAD_ARG;
-    }
-    return d1.dtype == GPP_BF16 ? gpp_tail_dispatch_bf16(d1, d2, next1x1 ? &d3 : nullptr, tile_rows, st)
-                                : gpp_tail_dispatch_f16(d1, d2, next1x1 ? &d3 : nullptr, tile_rows, st);
+    return d1.dtype == GPP_BF16 ? gpp_tail_dispatch_bf16(d1, d2, tile_rows, st) : gpp_tail_dispatch_f16(d1, d2, tile_rows, st);
 }
 
 }  // namespace
 
 extern "C" int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream)
 {
-    return tail_entry(conv3x3, conv1x1, nullptr, tile_rows, stream);
-}
-
-extern "C" int gpp_bottleneck_tail_next(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const gpp_conv_desc* next1x1,
-                                        int tile_rows, void* stream)
-{
-    if (!next1x1) return GPP_ERR_BAD_ARG;
-    return tail_entry(conv3x3, conv1x1, next1x1, tile_rows, stream);
+    return tail_entry(conv3x3, conv1x1, tile_rows, stream);
 }
 
 extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)
@@ -181,6 +163,49 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
     return dispatch_any(d, (hipStream_t)stream);
 }
 
+// The block tiles a layer may run with (same K order per output element in every one of them: the choice never changes a result).
+// One list for the autotuner below and for gpp_conv2d_tile_candidates (tests draw tiles at random from it).
+static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
+                             1128128, 1192128, 1128256, 1192256, 256256, 1256256,
+                             128160, 192160, 1192160, 2256256,
+                             128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
+// (the loader-wavefront form of round 2, tile codes 3064128 ..., measured 1.5 - 2x slower on every layer it was built for
+// (profiles/r2/ring_kernel.txt), is no longer part of the library)
+static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
+{
+    const int ck = 128 / elem_size(desc->dtype);
+    const int nk = desc->KH * desc->KW * (desc->C_in / ck);
+    int64_t rows = 0;
+    for (int g = 0; g < desc->n_groups; ++g) rows += (int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out;
+    const int bn = tile % 1000 ? tile % 1000 : 128;
+    if (tile >= 3000000) return false;
+    if (tile && bn == 64 && desc->C_out > 256) return false;        // narrow tiles on wide layers: never competitive
+    if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) return false;
+    // the pipelined loops need a few K-steps to pay; 16-bit types, and GPP_BF16X3 on a pre-split input map
+    const bool x3_pipe = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);
+    if (tile > 1000000 && tile < 3000000 && (nk < 4 || (f32_storage(desc->dtype) && !x3_pipe))) return false;
+    if (tile == 1256256 && !x3_pipe) return false;
+    if (x3_pipe && tile == 1192160) return false;
+    if (bn == 256 && desc->dtype == GPP_F32) return false;
+    if ((tile == 128256 || tile == 192256) && !is_x3(desc->dtype)) return false;
+    if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) return false;   // only where it cuts the N padding
+    if (tile == 2256256 && (desc->C_out < 384 || desc->C_out % 256 != 128 || rows < 256 * 16)) return false;   // dual-shape grid: C_out = 256 k + 128
+    return true;
+}
+
+extern "C" int gpp_conv2d_tile_candidates(const gpp_conv_desc* desc, int* tiles, int capacity, int* count)
+{
+    if (!desc || !count || (capacity > 0 && !tiles)) return GPP_ERR_BAD_ARG;
+    int n = 0;
+    for (int tile : kTiles) {
+        if (!tile_is_candidate(desc, tile)) continue;
+        if (n < capacity) tiles[n] = tile;
+        ++n;
+    }
+    *count = n;
+    return GPP_OK;
+}
+
 // Pick the fastest block tile for one layer by timing the candidates on the device (the layer is idempotent: it only
 // rewrites its own output).  The tile-count arithmetic (how many workgroups land on 256 CUs, in how many rounds) decides
 // most mid-sized layers and is not worth modelling: measure.  Writes the winner into desc->tile_hint.  The tile never
@@ -189,12 +214,6 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* best_us)
 {
     if (!desc || iters < 1) return GPP_ERR_BAD_ARG;
-    static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
-                                 1128128, 1192128, 1128256, 1192256, 256256, 1256256,
-                                 128160, 192160, 1192160, 2256256,
-                                 128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
-    // (the loader-wavefront form, tile codes 3064128 / 3096128 / 3128128 / 3064256 of conv_ring_impl.h, is not a candidate:
-    // measured 1.5 - 2x slower than the plain tiles on every latency-bound layer it was built for, profiles/r2/ring_kernel.txt)
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);
@@ -202,10 +221,6 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     e = hipEventCreate(&e1);
     if (e != hipSuccess) { (void)hipEventDestroy(e0); return (int)e; }
     const int tile_in = desc->tile_hint;
-    const int ck = 128 / elem_size(desc->dtype);
-    const int nk = desc->KH * desc->KW * (desc->C_in / ck);
-    int64_t rows = 0;
-    for (int g = 0; g < desc->n_groups; ++g) rows += (int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out;
     float best = 1e30f;
     int best_tile = tile_in, rc = GPP_OK;
     auto time_one = [&](int tile, float* us) -> int {
@@ -227,20 +242,7 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         return GPP_OK;
     };
     for (int tile : kTiles) {
-        const int bn = tile % 1000 ? tile % 1000 : 128;
-        if (tile >= 3000000 && f32_storage(desc->dtype)) continue;
-        if (tile && bn == 64 && desc->C_out > 256) continue;        // narrow tiles on wide layers: never competitive
-        if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) continue;
-        // the pipelined loops need a few K-steps to pay; 16-bit types, and GPP_BF16X3 on a pre-split input map
-        const bool x3_pipe = desc->dtype == GPP_BF16X3 && (desc->x3_split & GPP_X3_IN);
-        if (tile > 1000000 && tile < 3000000 && (nk < 4 || (f32_storage(desc->dtype) && !x3_pipe))) continue;
-        if (tile == 1256256 && !x3_pipe) continue;
-        if (x3_pipe && tile == 1192160) continue;
-        if (bn == 256 && desc->dtype == GPP_F32) continue;
-        if ((tile == 128256 || tile == 192256) && desc->dtype != GPP_BF16X3) continue;
-        if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) continue;   // only where it cuts the N padding
-        if (tile >= 3000000 && bn == 256 && desc->C_out < 192) continue;
-        if (tile == 2256256 && (desc->C_out < 384 || desc->C_out % 256 != 128 || rows < 256 * 16)) continue;   // dual-shape grid: C_out = 256 k + 128
+        if (!tile_is_candidate(desc, tile)) continue;
         float us = 0.0f;
         int r = time_one(tile, &us);
         if (r != GPP_OK) { if (tile == 0) { rc = r; break; } continue; }

@@ -1,0 +1,6 @@
+// Instantiates the implicit-GEMM convolution kernels (conv_igemm_impl.h) for one element type: GPP_F16X3
+// (float32 storage, three IEEE-half matrix products per float32 product: 11 + 11 significant bits per operand).
+#include "conv_igemm_impl.h"
+#include "conv_igemm_types.h"
+
+int gpp_conv_dispatch_f16x3(gpp_conv_desc& d, hipStream_t st) { return dispatch<GPP_F16X3>(d, st); }

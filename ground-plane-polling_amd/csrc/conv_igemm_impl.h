@@ -158,31 +158,61 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-// GPP_BF16X3 pre-split maps (gpp_conv_desc.x3_split): channels n .. n + 7 (n a multiple of 8) of the pixel whose float32-sized
-// element offset is `base` live at byte (base + (n & ~31)) * 4 + (n & 31) * 2 (8 bf16 hi) and 64 bytes further (8 bf16 lo).
+// The two "three 16-bit matrix products per float32 product" types: x = hi + lo with hi = h(x), lo = h(x - hi) (x - hi is exact in
+// float32), x * w ~ hi*whi + hi*wlo + lo*whi.  GPP_BF16X3: h = bfloat16, 8 + 8 significant bits, ~2^-16 per product, float32's
+// range.  GPP_F16X3: h = IEEE half, 11 + 11 bits, ~2^-22 per product (float32: 2^-24); range: activations are clamped to +-65504
+// before the split (a finite wrong value instead of inf for an activation no sane checkpoint produces), weights are scaled per
+// output channel by a power of two so that both halves are normal halfs (gpp_conv_desc.out_scale undoes it in the epilogue).
+template <int DT> constexpr bool kX3 = (DT == GPP_BF16X3 || DT == GPP_F16X3);
+// every other type: placeholders so that discarded `if constexpr` branches still parse
+template <int DT> struct X3Half {      // primary template
+    using half = __bf16;
+    using vec = bf16x8;
+    static __device__ __forceinline__ f32x4 mfma(vec, vec, f32x4 c) { return c; }
+    static __device__ __forceinline__ float clamp(float x) { return x; }
+};
+
+template <> struct X3Half<GPP_BF16X3> {
+    using half = __bf16;
+    using vec = bf16x8;
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float clamp(float x) { return x; }
+};
+template <> struct X3Half<GPP_F16X3> {
+    using half = _Float16;
+    using vec = f16x8;
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float clamp(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
+};
+// Pre-split maps (gpp_conv_desc.x3_split): channels n .. n + 7 (n a multiple of 8) of the pixel whose float32-sized
+// element offset is `base` live at byte (base + (n & ~31)) * 4 + (n & 31) * 2 (8 halves hi) and 64 bytes further (8 halves lo).
 __device__ __forceinline__ const char* x3_addr(const void* buf, int64_t base, int n)
 {
     return (const char*)buf + ((base + (n & ~31)) << 2) + ((n & 31) << 1);
 }
+template <int DT>
 __device__ __forceinline__ void x3_unpack(const f32x4 hi_bits, const f32x4 lo_bits, float (&r)[8])
 {
-    union { f32x4 f; bf16x8 b; } h, l;
+    union { f32x4 f; typename X3Half<DT>::vec b; } h, l;
     h.f = hi_bits;
     l.f = lo_bits;
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = (float)h.b[e] + (float)l.b[e];
 }
+template <int DT>
 __device__ __forceinline__ void x3_store(void* buf, int64_t base, int n, const float (&v)[8])
 {
-    bf16x8 h, l;
+    using half = typename X3Half<DT>::half;
+    typename X3Half<DT>::vec h, l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        h[e] = (__bf16)v[e];
-        l[e] = (__bf16)(v[e] - (float)h[e]);
+        const float x = X3Half<DT>::clamp(v[e]);
+        h[e] = (half)x;
+        l[e] = (half)(x - (float)h[e]);
     }
     char* p = (char*)x3_addr(buf, base, n);
-    *(bf16x8*)p = h;
-    *(bf16x8*)(p + 64) = l;
+    *(typename X3Half<DT>::vec*)p = h;
+    *(typename X3Half<DT>::vec*)(p + 64) = l;
 }
 
 // Finish 8 consecutive output channels of one output pixel: (+ residual through the optional TF
@@ -194,11 +224,11 @@ __device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], i
     using vec8 = typename Elem<DT>::vec8;
     using scalar = typename Elem<DT>::scalar;
     const bool full = (n + 8 <= d.C_out);
-    if constexpr (DT == GPP_BF16X3) {
+    if constexpr (kX3<DT>) {
         if (rrow && (d.x3_split & GPP_X3_RES)) {            // pre-split shortcut map (whole 8-channel groups by construction)
             const char* p = x3_addr(rrow, 0, n);
             float r[8];
-            x3_unpack(*(const f32x4*)p, *(const f32x4*)(p + 64), r);
+            x3_unpack<DT>(*(const f32x4*)p, *(const f32x4*)(p + 64), r);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r[e];
             rrow = nullptr;
@@ -217,9 +247,9 @@ __device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], i
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
     }
-    if constexpr (DT == GPP_BF16X3) {
+    if constexpr (kX3<DT>) {
         if (d.x3_split & GPP_X3_OUT) {                      // (validated: not out_f32, C_out a multiple of 32)
-            x3_store(d.out, obase, n, v);
+            x3_store<DT>(d.out, obase, n, v);
             return;
         }
     }
@@ -250,10 +280,10 @@ __device__ __forceinline__ void finish8_pre(const gpp_conv_desc& d, float (&v)[8
     using scalar = typename Elem<DT>::scalar;
     if (has_res) {
         bool done = false;
-        if constexpr (DT == GPP_BF16X3) {
+        if constexpr (kX3<DT>) {
             if (d.x3_split & GPP_X3_RES) {                  // the prefetched registers hold the raw [8 hi][8 lo] bits
                 float r[8];
-                x3_unpack(rv.lo, rv.hi, r);
+                x3_unpack<DT>(rv.lo, rv.hi, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
                 done = true;
@@ -268,9 +298,9 @@ __device__ __forceinline__ void finish8_pre(const gpp_conv_desc& d, float (&v)[8
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
     }
-    if constexpr (DT == GPP_BF16X3) {
+    if constexpr (kX3<DT>) {
         if (d.x3_split & GPP_X3_OUT) {
-            x3_store(d.out, obase, n, v);
+            x3_store<DT>(d.out, obase, n, v);
             return;
         }
     }
@@ -345,38 +375,42 @@ __device__ __forceinline__ RowAddr row_addr_at(const gpp_conv_desc& d, const Pix
 // exact in float32), x * w ~ hi*whi + hi*wlo + lo*whi; the dropped lo*wlo term and the two roundings of lo leave a relative
 // error of about 2^-16 per product -- 2^8 closer to float32 than plain bf16 operands, at a third of the bf16 matrix rate.
 // Activations are split in registers on their way from LDS to the matrix pipe; weights are stored pre-split.
-template <> struct Elem<GPP_BF16X3> {
+template <int DT> struct ElemX3 {
     using scalar = float;
     using vec8 = f32x8;
     using frag = f32x4;
     static constexpr int ESZ = 4;
     static __device__ __forceinline__ vec8 pack(const float (&v)[8]) { return Elem<GPP_F32>::pack(v); }
     static __device__ __forceinline__ f32x4 mfma(frag, frag, f32x4 c) { return c; }      // unused: the K-step has its own form
-    // 8 consecutive float32 K values -> their bf16 hi and lo parts (round to nearest even, v_cvt_pk_bf16_f32)
-    static __device__ __forceinline__ void split(const f32x4 x0, const f32x4 x1, bf16x8& hi, bf16x8& lo)
+    // 8 consecutive float32 K values -> their hi and lo halves (round to nearest even)
+    static __device__ __forceinline__ void split(const f32x4 x0, const f32x4 x1, typename X3Half<DT>::vec& hi, typename X3Half<DT>::vec& lo)
     {
+        using half = typename X3Half<DT>::half;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float x = e < 4 ? x0[e] : x1[e - 4];
-            const __bf16 h = (__bf16)x;
+            const float x = X3Half<DT>::clamp(e < 4 ? x0[e] : x1[e - 4]);
+            const half h = (half)x;
             hi[e] = h;
-            lo[e] = (__bf16)(x - (float)h);
+            lo[e] = (half)(x - (float)h);
         }
     }
 };
+template <> struct Elem<GPP_BF16X3> : ElemX3<GPP_BF16X3> {};
+template <> struct Elem<GPP_F16X3> : ElemX3<GPP_F16X3> {};
 
-template <int DT> constexpr bool kF32Storage = (DT == GPP_F32 || DT == GPP_BF16X3);
+template <int DT> constexpr bool kF32Storage = (DT == GPP_F32 || DT == GPP_BF16X3 || DT == GPP_F16X3);
 
 // XIN (GPP_BF16X3 only): the input map is pre-split (gpp_conv_desc.x3_split & GPP_X3_IN) -- a compile-time property of the kernel, so
 // that the loop of either form carries no trace of the other (the 256 x 256 tile has no registers to spare for both)
 template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool XIN = false>
 __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const int block_x, const int grid_x)
 {
-    static_assert(!XIN || DT == GPP_BF16X3, "pre-split input maps: GPP_BF16X3");
+    static_assert(!XIN || kX3<DT>, "pre-split input maps: GPP_BF16X3 / GPP_F16X3");
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
     using frag = typename E::frag;
     using scalar = typename E::scalar;
+    using xh8 = typename X3Half<DT>::vec;                // GPP_BF16X3 / GPP_F16X3: 8 halves of a fragment
     constexpr int ESZ = E::ESZ, CK = kRowBytes / ESZ;     // bytes per element, channels per K-step
     constexpr int NW = WM * WN;                          // wavefronts per workgroup
     constexpr int MF = BM / WM / 16, NF = BN / WN / 16;  // 16x16 accumulators per wave: MF x NF
@@ -439,7 +473,12 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     // only used when the tap is valid) and a validity mask: bit kh = input row iy0+kh inside the
     // image, bit 8+kw = input column ix0+kw inside.  Per K-step the source is base + (kh*W + kw)*pitch
     // (a scalar) when both bits are set, else kOutOfRange: ~4 VALU per row and step.
-    int a_base[A_IT], a_mask[A_IT], a_voff[A_IT];
+    // VOFF_INLINE (the 512 x 128 side of the dual-shape grid: 8 activation pieces per wavefront): the tap's offsets are not kept in
+    // a register per piece but formed from (a_base, a_mask) and the tap's two scalars when the piece is issued -- the same
+    // arithmetic, 8 registers less (that form spilled 8 registers of the dual kernel to scratch)
+    constexpr bool VOFF_INLINE = PIPE && A_IT >= 8;
+    int a_base[A_IT], a_mask[A_IT], a_voff[VOFF_INLINE ? 1 : A_IT];
+    int tap_delta = 0, tap_need = 0;
     const int pitch2 = d.in_pitch * ESZ;                // bytes per input pixel
     {
         PixWalk pw;                                     // rows m, m + 8, m + 16, ...: one pair of divisions, then a walk
@@ -469,15 +508,23 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     auto set_tap = [&](int kh, int kw) {
         const int delta = (kh * W_in + kw) * pitch2;
         const int need = (1 << kh) | (1 << (8 + kw));
+        if constexpr (VOFF_INLINE) {
+            tap_delta = delta; tap_need = need;
+        } else {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) a_voff[i] = ((a_mask[i] & need) == need) ? a_base[i] + delta : kOutOfRange;
+            for (int i = 0; i < A_IT; ++i) a_voff[i] = ((a_mask[i] & need) == need) ? a_base[i] + delta : kOutOfRange;
+        }
+    };
+    auto voff_of = [&](int i) {
+        if constexpr (VOFF_INLINE) return ((a_mask[i] & tap_need) == tap_need) ? a_base[i] + tap_delta : kOutOfRange;
+        else return a_voff[i];
     };
     // per K-step: only scalar offsets change (cc*128 bytes into the pixel, ks*128 bytes into the weight row)
     auto stage = [&](int buf, int cc, int ks) {
         unsigned char* sa = smem + buf * STAGE + wave * A_IT * 8 * kRowBytes;
         unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) glds16(in_rsrc, a_voff[i], cc * kRowBytes, sa + i * 8 * kRowBytes);
+        for (int i = 0; i < A_IT; ++i) glds16(in_rsrc, voff_of(i), cc * kRowBytes, sa + i * 8 * kRowBytes);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) glds16(w_rsrc, w_voff[i], ks * kRowBytes, sb + i * 8 * kRowBytes);
     };
@@ -507,7 +554,9 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     // ---- shortcut prefetch (small non-pipelined tiles only: the layers that carry a residual are the 1x1 "branch2c" /
     // FPN lateral convs with 4-16 K-steps, where load -> wait -> add -> store in the epilogue is a large part of a
     // workgroup's life): the residual rows of this tile are requested now and are in registers when the loop ends
-    constexpr bool RESPRE = !PIPE && (MF * NF / 2 <= 10);
+    // (a float32-storage row piece is 8 registers, a 16-bit one 4: the 160 x 128 / 128 x 160 float32 tiles spilled 60 - 150 registers
+    // to scratch with the prefetch, tools/isa_audit.py)
+    constexpr bool RESPRE = !PIPE && (MF * NF / 2 <= (ESZ == 4 ? 8 : 10));
     vec8 rpre[RESPRE ? MF : 1][RESPRE ? NF / 2 : 1];
     RowAddr ra_pre[RESPRE ? MF : 1];
     const bool use_pre = RESPRE && d.residual != nullptr && gridDim.y == 1 && (d.C_out & 7) == 0;
@@ -526,7 +575,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                     const int n = n0 + wn * (BN / WN) + jj * 32 + (lane >> 4) * 8;
                     const int nc = n < d.C_out ? n : 0;
                     bool raw = false;
-                    if constexpr (DT == GPP_BF16X3) {
+                    if constexpr (kX3<DT>) {
                         if (d.x3_split & GPP_X3_RES) {          // pre-split shortcut map: the two 16-byte halves as they are
                             const char* p = x3_addr(d.residual, ra_pre[i].rbase, nc);
                             rpre[i][jj].lo = *(const f32x4*)p;
@@ -545,15 +594,30 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     constexpr int COLS = BN / WN;                        // output channels owned by this wave
     static_assert(NF % 2 == 0, "N tiles come in interleaved pairs");
     float bias_v[NF / 2][8];
+    // GPP_F16X3: the packed weights of output channel n are 2^k(n) times the real ones (both halves normal halfs); out_scale[n] =
+    // 2^-k(n) brings the accumulator back before the bias is added (an exact multiplication)
+    constexpr bool OSCALE = (DT == GPP_F16X3);
+    float scale_v[OSCALE ? NF / 2 : 1][8];
     auto load_bias = [&]() {
 #pragma unroll
         for (int jj = 0; jj < NF / 2; ++jj) {
             const int n = n0 + wn * COLS + jj * 32 + (lane >> 4) * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) bias_v[jj][e] = (d.bias && n + e < d.C_out) ? d.bias[n + e] : 0.0f;
+            if constexpr (OSCALE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) scale_v[jj][e] = (d.out_scale && n + e < d.C_out) ? d.out_scale[n + e] : 1.0f;
+            }
         }
     };
-    if constexpr (!PIPE) load_bias();
+    auto comb = [&](float a, int jj, int e) {
+        if constexpr (OSCALE) return a * scale_v[jj][e] + bias_v[jj][e];
+        else return a + bias_v[jj][e];
+    };
+    // (... and only where it costs at most 16 registers beside at most 96 accumulator registers: the 160-column tiles (40 registers
+    // of bias) and the plain 256 x 256 tile spilled with it)
+    constexpr bool BIASPRE = !PIPE && NF <= 4 && MF * NF <= 24 && DT != GPP_F16X3;      // (GPP_F16X3 fetches bias AND scale: in the epilogue)
+    if constexpr (BIASPRE) load_bias();
 
     GPP_STAMP(1);
     // ---- main loop.  Ring of STAGES buffers, PF = STAGES-1 K-steps of LDS-DMA in flight; one raw
@@ -624,7 +688,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         auto issue_one = [&](int idx, int buf, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int so_a, int so_w) {
             unsigned char* sa = smem + buf * STAGE + wave * A_IT * 8 * kRowBytes;
             unsigned char* sb = smem + buf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
-            if (idx < A_IT) glds16(ra, a_voff[idx < A_IT ? idx : 0], so_a, sa + idx * 8 * kRowBytes);
+            if (idx < A_IT) glds16(ra, voff_of(idx < A_IT ? idx : 0), so_a, sa + idx * 8 * kRowBytes);
             else glds16(rw, w_voff[idx >= A_IT ? idx - A_IT : 0], so_w, sb + (idx - A_IT) * 8 * kRowBytes);
         };
         auto advance_tap = [&]() {
@@ -635,7 +699,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             set_tap(kh, kw);
             ++issued;
         };
-        if constexpr (DT == GPP_BF16X3) {
+        if constexpr (kX3<DT>) {
             // ---- pre-split bf16x3 (XIN): a K-step is 32 channels = one k-slice, three matrix products per accumulator, three phases:
             //   phase A:  MFMA(hi * wlo)  ||  LDS reads of whi (this stage)
             //   phase B:  MFMA(hi * whi)  ||  LDS reads of lo  (this stage)
@@ -645,7 +709,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             // it, so the four sets take 96 registers (as in the 16-bit loop) and the body needs no second copy.  One barrier per
             // 3 MF NF MFMAs; the DMA of stage k+2 has two phases to land.
             static_assert(XIN, "the pipelined bf16x3 loop reads pre-split activation rows");
-            bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
+            xh8 ah[MF], al[MF], bh[NF], bl[NF];
 #pragma unroll
             for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 0, in_rsrc, w_rsrc, cc * kRowBytes, ks0 * kRowBytes);
             advance_tap();
@@ -660,9 +724,9 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 if (live) advance_tap();
             }
 #pragma unroll
-            for (int i = 0; i < MF; ++i) ah[i] = *(const bf16x8*)(smem + a_rd[0] + i * 16 * kRowBytes);
+            for (int i = 0; i < MF; ++i) ah[i] = *(const xh8*)(smem + a_rd[0] + i * 16 * kRowBytes);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) bl[j] = *(const bf16x8*)(smem + b_rd[1] + j * 16 * kRowBytes);
+            for (int j = 0; j < NF; ++j) bl[j] = *(const xh8*)(smem + b_rd[1] + j * 16 * kRowBytes);
             if (NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
             for (int ks = 0; ks < nk; ++ks) {
                 const int cur = ks & 1;
@@ -676,17 +740,17 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
 #pragma unroll
                 for (int g = 0; g < MF; ++g) {
 #pragma unroll
-                    for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) bh[j] = *(const bf16x8*)(scur + b_rd[0] + j * 16 * kRowBytes);
+                    for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) bh[j] = *(const xh8*)(scur + b_rd[0] + j * 16 * kRowBytes);
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[g], acc[g][j], 0, 0, 0);
+                    for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bl[j], ah[g], acc[g][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- phase B: hi * whi, fetch lo
 #pragma unroll
                 for (int g = 0; g < MF; ++g) {
-                    al[g] = *(const bf16x8*)(scur + a_rd[1] + g * 16 * kRowBytes);
+                    al[g] = *(const xh8*)(scur + a_rd[1] + g * 16 * kRowBytes);
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[g], acc[g][j], 0, 0, 0);
+                    for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bh[j], ah[g], acc[g][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -699,11 +763,11 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 for (int g = 0; g < MF; ++g) {
 #pragma unroll
                     for (int idx = g * PER_STAGE / MF; idx < (g + 1) * PER_STAGE / MF; ++idx) issue_one(idx, cur, ra, rw, so_a, so_w);
-                    ah[g] = *(const bf16x8*)(snxt + a_rd[0] + g * 16 * kRowBytes);
+                    ah[g] = *(const xh8*)(snxt + a_rd[0] + g * 16 * kRowBytes);
 #pragma unroll
-                    for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) bl[j] = *(const bf16x8*)(snxt + b_rd[1] + j * 16 * kRowBytes);
+                    for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) bl[j] = *(const xh8*)(snxt + b_rd[1] + j * 16 * kRowBytes);
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[g], acc[g][j], 0, 0, 0);
+                    for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bh[j], al[g], acc[g][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (live) advance_tap();
@@ -813,27 +877,27 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         if (issued < nk) issue_next();
 #endif
         {
-            if constexpr (DT == GPP_BF16X3) {
+            if constexpr (kX3<DT>) {
                 // one 32-channel K-step = one k-slice of v_mfma_f32_16x16x32_bf16, three matrix products per accumulator
                 const unsigned char* sbase = smem + cbuf * STAGE;
-                bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
+                xh8 ah[MF], al[MF], bh[NF], bl[NF];
                 if constexpr (XIN) {
                     // pre-split activations: the row holds [32 bf16 hi | 32 bf16 lo], exactly as the weight rows do
 #pragma unroll
                     for (int i = 0; i < MF; ++i) {
-                        ah[i] = *(const bf16x8*)(sbase + a_rd[0] + i * 16 * kRowBytes);
-                        al[i] = *(const bf16x8*)(sbase + a_rd[1] + i * 16 * kRowBytes);
+                        ah[i] = *(const xh8*)(sbase + a_rd[0] + i * 16 * kRowBytes);
+                        al[i] = *(const xh8*)(sbase + a_rd[1] + i * 16 * kRowBytes);
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < MF; ++i)
-                        Elem<GPP_BF16X3>::split(*(const f32x4*)(sbase + a_rdx[0] + i * 16 * kRowBytes),
+                        Elem<DT>::split(*(const f32x4*)(sbase + a_rdx[0] + i * 16 * kRowBytes),
                                                 *(const f32x4*)(sbase + a_rdx[1] + i * 16 * kRowBytes), ah[i], al[i]);
                 }
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    bh[j] = *(const bf16x8*)(sbase + b_rd[0] + j * 16 * kRowBytes);
-                    bl[j] = *(const bf16x8*)(sbase + b_rd[1] + j * 16 * kRowBytes);
+                    bh[j] = *(const xh8*)(sbase + b_rd[0] + j * 16 * kRowBytes);
+                    bl[j] = *(const xh8*)(sbase + b_rd[1] + j * 16 * kRowBytes);
                 }
                 // per accumulator and K-step: hi * wlo, hi * whi, lo * whi -- the order of the software-pipelined form below (its
                 // three phases), so that every bf16x3 tile sums an output element in the same order
@@ -841,13 +905,13 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
                     for (int j = 0; j < NF; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = X3Half<DT>::mfma(bl[j], ah[i], acc[i][j]);
+                        acc[i][j] = X3Half<DT>::mfma(bh[j], ah[i], acc[i][j]);
                     }
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NF; ++j) acc[i][j] = X3Half<DT>::mfma(bh[j], al[i], acc[i][j]);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -888,7 +952,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     // runs the epilogue without per-lane conditions (the general form costs ~280 exec-mask branches per wavefront: 6 us of a
     // 256 x 256 tile's life, a quarter of a 18-K-step tile's) and walks the output rows instead of dividing per row.
     const bool interior = (m0 + BM <= Mg) && (n0 + BN <= d.C_out) && ((d.C_out & 7) == 0);
-    if constexpr (PIPE) load_bias();
+    if constexpr (!BIASPRE) load_bias();
     if constexpr (RESPRE) {
         if (use_pre && interior) {
 #pragma unroll
@@ -898,8 +962,8 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
-                        v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
+                        v[e] = comb(acc[i][2 * jj][e], jj, e);
+                        v[4 + e] = comb(acc[i][2 * jj + 1][e], jj, 4 + e);
                     }
                     finish8_pre<DT>(d, v, n0 + wn * COLS + jj * 32 + fq * 8, ra_pre[i].obase, true, rpre[i][jj]);
                 }
@@ -919,8 +983,8 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
-                        v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
+                        v[e] = comb(acc[i][2 * jj][e], jj, e);
+                        v[4 + e] = comb(acc[i][2 * jj + 1][e], jj, 4 + e);
                     }
                     finish8_pre<DT>(d, v, n, ra_pre[i].obase, true, rpre[i][jj]);
                 }
@@ -941,8 +1005,8 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
-                    v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
+                    v[e] = comb(acc[i][2 * jj][e], jj, e);
+                    v[4 + e] = comb(acc[i][2 * jj + 1][e], jj, 4 + e);
                 }
                 finish8_pre<DT>(d, v, n0 + wn * COLS + jj * 32 + fq * 8, obase, false, typename E::vec8());
             }
@@ -968,8 +1032,8 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = acc[i][2 * jj][e] + bias_v[jj][e];
-                v[4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
+                v[e] = comb(acc[i][2 * jj][e], jj, e);
+                v[4 + e] = comb(acc[i][2 * jj + 1][e], jj, 4 + e);
             }
             finish8<DT>(d, v, n, ra.obase, rrow);
         }
@@ -1037,6 +1101,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const gpp_conv_desc 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
     }
+    if constexpr (DT == GPP_F16X3) {
+        if (d.out_scale) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (n + k < d.C_out) v[k] *= d.out_scale[n + k];
+        }
+    }
     if (d.bias) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (n + k < d.C_out) v[k] += d.bias[n + k];
@@ -1055,24 +1125,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const gpp_conv_desc 
 // HBM-bound; results are bit-identical to the two separate launches (same K order, same rounding).
 // d1 = descriptor of the 3x3 layer (its `out` is not written), d2 = descriptor of the 1x1 layer.
 //
-// NEXT = true additionally computes the FIRST layer of the following bottleneck, z = relu(W3 * y + b3) (1x1, 4*CMID ->
-// CMID, "branch2a" of the next identity block, descriptor d3): in phase 2 every wavefront then owns BM/4 full rows of
-// the y tile (4 x 1 layout), and after bias + shortcut + ReLU + rounding its registers hold exactly the MFMA activation
-// fragments of those rows (lane (q, c): pixel c, 8 consecutive channels 8q..8q+7 of a 32-channel slice), so y feeds
-// the next matrix product straight from registers while it is being stored; W3 fragments come from L2 one slice ahead.
-// Channel slices are consumed in ascending order, the order of the stand-alone layer's K-steps: z is bit-identical to
-// launching that layer on the stored y.  Saves that launch and its read of y (138 MB per res2 block at B = 8).
-template <int DT, int BM, int CMID, bool NEXT>
-__global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2, const gpp_conv_desc d3)
+// (Round 2 also carried a form that computed the FOLLOWING block's first 1x1 layer in the same launch: bit-identical, measured
+// slower than the separate launch -- C = 64: 137 us against 92 + 36 -- and removed in round 3.)
+template <int DT, int BM, int CMID>
+__global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2)
 {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
     using scalar = typename E::scalar;
     constexpr int WM = 2, WN = 2, NW = 4;
-    constexpr int P2M = NEXT ? 4 : 2, P2N = NEXT ? 1 : 2;                  // wavefront layout of phase 2
+    constexpr int P2M = 2, P2N = 2;                                        // wavefront layout of phase 2
     constexpr int MF = BM / WM / 16, NF1 = CMID / WN / 16;
     constexpr int MF2 = BM / P2M / 16, NF2 = 128 / P2N / 16, COLS2 = 128 / P2N;   // phase 2: BM x 128 output tiles
-    constexpr int NZ = CMID / 16;                                          // phase 3: 16-channel tiles of z
     static_assert(BM % (16 * P2M) == 0, "phase-2 wave tile");
     constexpr int KC = CMID / 64;                                          // 64-channel chunks of the intermediate
     constexpr int A_BYTES = BM * kRowBytes, B_BYTES = CMID * kRowBytes, STAGE = A_BYTES + B_BYTES;
@@ -1264,23 +1328,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
     GPP_STAMP(2);
     // ---- phase 2: y tile = T (BM x CMID) * W2^T, 128 output channels at a time
     const int n2_tiles = d2.C_out / 128;
-    // phase 3 state (NEXT): z accumulators and the W3 fragments of the current 32-channel slice (lane (q, r): stored row
-    // 16*j + r of W3, bytes of channels slice*32 + 8q .. 8q+7), fetched from L2 one slice ahead
-    f32x4 zacc[NEXT ? MF2 : 1][NEXT ? NZ : 1];
-    vec8 w3f[NEXT ? NZ : 1];
-    const scalar* w3 = (const scalar*)d3.weight;
-    const int K3 = d3.C_in;
-    auto load_w3 = [&](vec8 (&dst)[NEXT ? NZ : 1], int slice) {
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) dst[j] = *(const vec8*)(w3 + (int64_t)(j * 16 + frow) * K3 + slice * 32 + fq * 8);
-    };
-    if constexpr (NEXT) {
-#pragma unroll
-        for (int i = 0; i < MF2; ++i)
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        load_w3(w3f, 0);
-    }
     for (int t = 0; t < n2_tiles; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1330,32 +1377,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
 #pragma unroll
                     for (int e = 0; e < 8; ++e) outv[i][jj][e] += (float)rpre[i][jj][e];
                 }
-                if (NEXT && d2.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) outv[i][jj][e] = fmaxf(outv[i][jj][e], 0.0f);
-                }
             }
         }
         if (res && t + 1 < n2_tiles) prefetch_res(t + 1);
-        if constexpr (NEXT) {
-            // phase 3: the rounded y values are the activation fragments of the next 1x1 layer
-#pragma unroll
-            for (int jj = 0; jj < NF2 / 2; ++jj) {
-                const int slice = t * (NF2 / 2) + jj;
-                vec8 w3n[NZ];
-                if (slice + 1 < n2_tiles * (NF2 / 2)) load_w3(w3n, slice + 1);
-#pragma unroll
-                for (int i = 0; i < MF2; ++i) {
-                    vec8 yf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) yf[e] = (scalar)outv[i][jj][e];
-#pragma unroll
-                    for (int j = 0; j < NZ; ++j) zacc[i][j] = E::mfma(w3f[j], yf, zacc[i][j]);
-                }
-#pragma unroll
-                for (int j = 0; j < NZ; ++j) w3f[j] = w3n[j];
-            }
-        }
 #pragma unroll
         for (int jj = 0; jj < NF2 / 2; ++jj) {
             const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
@@ -1364,30 +1388,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
                 const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
                 if (m >= Mg) continue;
                 finish8_pre<DT>(d2, outv[i][jj], n, ra[i].obase, false, rpre[i][jj]);
-            }
-        }
-    }
-    if constexpr (NEXT) {
-        // z = relu(zacc + b3): pairs of 16-row W3 tiles give every lane 8 consecutive output channels, as everywhere
-        const gpp_conv_group& G3 = d3.groups[0];
-#pragma unroll
-        for (int q = 0; q < NZ / 2; ++q) {
-            const int n3 = q * 32 + fq * 8;
-            float bias_v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias_v[e] = d3.bias ? d3.bias[n3 + e] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < MF2; ++i) {
-                const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
-                if (m >= Mg) continue;
-                const int b = m / HW, p = m - b * HW;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = zacc[i][2 * q][e] + bias_v[e];
-                    v[4 + e] = zacc[i][2 * q + 1][e] + bias_v[4 + e];
-                }
-                finish8_pre<DT>(d3, v, n3, G3.out_off + (int64_t)b * G3.out_bstride + (int64_t)p * d3.out_pitch, false, w3f[0]);
             }
         }
     }
@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_kernel(const gpp_conv_
 template <int BM, int BN>
 int prepare(gpp_conv_desc& d)
 {
-    const int esz = (d.dtype == GPP_F32 || d.dtype == GPP_BF16X3) ? 4 : 2;
+    const int esz = (d.dtype == GPP_F32 || d.dtype == GPP_BF16X3 || d.dtype == GPP_F16X3) ? 4 : 2;
     if (d.weight_rows < ((d.C_out + BN - 1) / BN) * BN) return GPP_ERR_BAD_ARG;
     int64_t in_elems = 0;
     for (int g = 0; g < d.n_groups; ++g) {
@@ -1448,7 +1448,7 @@ struct DeviceOnce {
 template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool XIN = false>
 int launch(gpp_conv_desc& d, hipStream_t st)
 {
-    if constexpr (DT == GPP_BF16X3 && !XIN) {
+    if constexpr (kX3<DT> && !XIN) {
         if (d.x3_split & GPP_X3_IN) return launch<DT, BM, BN, WM, WN, STAGES, PIPE, true>(d, st);      // the pre-split-input form of this tile
     }
     constexpr int lds = STAGES * (BM + BN) * kRowBytes;
@@ -1475,7 +1475,9 @@ int launch(gpp_conv_desc& d, hipStream_t st)
     // a layer with fewer K-steps than ring slots (1x1 convs with C_in = 64) only touches the first slots:
     // declaring just those lets more workgroups share a CU, which is what the HBM-bound layers need
     const int steps = (nk + nsplit - 1) / nsplit;
-    const int lds_used = (steps < STAGES ? steps : STAGES) * (BM + BN) * kRowBytes;
+    // (the pipelined loops always stage and read both buffers: they get the whole ring and need two K-steps per split)
+    if (PIPE && nk / nsplit < 2) return GPP_ERR_UNSUPPORTED;
+    const int lds_used = PIPE ? lds : (steps < STAGES ? steps : STAGES) * (BM + BN) * kRowBytes;
     kernel<<<dim3((unsigned)(tiles * n_tiles), (unsigned)nsplit), dim3(64 * WM * WN), lds_used, st>>>(d);
     if (nsplit > 1) {
         const int64_t total = (int64_t)d.partial_rows * ((d.C_out + 7) / 8);
@@ -1490,7 +1492,7 @@ template <int DT>
 int launch_dual(const gpp_conv_desc& d, hipStream_t st)
 {
     // 16-bit types, and GPP_BF16X3 on a pre-split input map (its pipelined three-phase loop)
-    constexpr bool X3 = (DT == GPP_BF16X3);
+    constexpr bool X3 = kX3<DT>;
     constexpr int ESZ = Elem<DT>::ESZ, CK = kRowBytes / ESZ;
     if (X3 && !(d.x3_split & GPP_X3_IN)) return GPP_ERR_UNSUPPORTED;
     if (d.C_out < 384 || d.C_out % 256 != 128 || d.KH * d.KW * (d.C_in / CK) < 2 || d.split_k > 1) return GPP_ERR_UNSUPPORTED;
@@ -1506,6 +1508,7 @@ int launch_dual(const gpp_conv_desc& d, hipStream_t st)
     d1.weight = (const char*)d.weight + (int64_t)head * d.KH * d.KW * d.C_in * ESZ;
     d1.weight_rows = d.weight_rows - head;
     if (d.bias) d1.bias = d.bias + head;
+    if (d.out_scale) d1.out_scale = d.out_scale + head;
     for (int g = 0; g < d.n_groups; ++g) {
         d1.groups[g].out_off += head;
         d1.groups[g].res_off += head;
@@ -1545,7 +1548,14 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
         // (regression outputs: 144 -> 160 instead of 256 columns; measured 200 -> 162 us).  96-wide tiles and 3/4-deep
         // LDS rings on the small tiles were measured too and lost everywhere (fewer workgroups per CU).
         case 128160: return launch<DT, 128, 160, 4, 1, 2, false>(d, st);
-        case 192160: return launch<DT, 192, 160, 4, 1, 2, false>(d, st);
+        case 192160:
+            if constexpr (kX3<DT>) {
+                // float32-input form of this tile: 3 registers over the budget (scratch); only the pre-split form exists
+                if (!(d.x3_split & GPP_X3_IN)) return GPP_ERR_UNSUPPORTED;
+                return launch<DT, 192, 160, 4, 1, 2, false, true>(d, st);
+            } else {
+                return launch<DT, 192, 160, 4, 1, 2, false>(d, st);
+            }
         case 0: break;
         default:
             // the software-pipelined / 8-wavefront forms exist for the 16-bit types only: the float32 path is bound by the
@@ -1570,7 +1580,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
             } else {
                 // GPP_BF16X3 spends 3 MFMAs per fragment pair: with 4-wavefront tiles its LDS traffic equals its matrix time;
                 // the 8-wavefront 256-column tiles (plain two-buffer loop) halve the LDS bytes per MFMA
-                if constexpr (DT == GPP_BF16X3) {
+                if constexpr (kX3<DT>) {
                     if (d.x3_split & GPP_X3_IN) {
                         // the software-pipelined three-phase loop: pre-split input maps only (1000000 + tile, as for the 16-bit types)
                         switch (d.tile_hint) {
@@ -1612,12 +1622,12 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
     return launch<DT, 128, 128, 2, 2, 2, false>(d, st);
 }
 
-template <int DT, int BM, int CMID, bool NEXT>
-int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, hipStream_t st)
+template <int DT, int BM, int CMID>
+int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, hipStream_t st)
 {
     constexpr int lds = 2 * (BM + CMID) * kRowBytes;
     static DeviceOnce once;
-    auto kernel = bottleneck_tail_kernel<DT, BM, CMID, NEXT>;
+    auto kernel = bottleneck_tail_kernel<DT, BM, CMID>;
     int rc = once.configure(kernel, lds);
     if (rc != GPP_OK) return rc;
     const gpp_conv_group& G = d1.groups[0];
@@ -1629,28 +1639,20 @@ int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, hipStre
     d1.weight_bytes = (int32_t)w1_bytes;
     d2.weight_bytes = (int32_t)w2_bytes;
     const int64_t rows = (int64_t)d1.batch * G.H_out * G.W_out;
-    kernel<<<dim3((unsigned)((rows + BM - 1) / BM)), dim3(256), lds, st>>>(d1, d2, d3);
+    kernel<<<dim3((unsigned)((rows + BM - 1) / BM)), dim3(256), lds, st>>>(d1, d2);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }
 
 template <int DT>
-int dispatch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc* d3, int tile_rows, hipStream_t st)
+int dispatch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st)
 {
     const bool c64 = d1.C_in == 64;
-    if (d3) {                            // + first layer of the next block: phase 2 is 4 x 1 wavefronts, BM / 4 rows each
-        switch (tile_rows) {
-            case 64: return c64 ? launch_tail<DT, 64, 64, true>(d1, d2, *d3, st) : launch_tail<DT, 64, 128, true>(d1, d2, *d3, st);
-            case 0: return c64 ? launch_tail<DT, 128, 64, true>(d1, d2, *d3, st) : launch_tail<DT, 64, 128, true>(d1, d2, *d3, st);
-            case 128: return c64 ? launch_tail<DT, 128, 64, true>(d1, d2, *d3, st) : GPP_ERR_UNSUPPORTED;   // C = 128: 64 rows only (registers)
-            default: return GPP_ERR_BAD_ARG;
-        }
-    }
     switch (tile_rows) {
-        case 96: return c64 ? launch_tail<DT, 96, 64, false>(d1, d2, d2, st) : launch_tail<DT, 96, 128, false>(d1, d2, d2, st);
+        case 96: return c64 ? launch_tail<DT, 96, 64>(d1, d2, st) : launch_tail<DT, 96, 128>(d1, d2, st);
         case 0:
-        case 128: return c64 ? launch_tail<DT, 128, 64, false>(d1, d2, d2, st) : launch_tail<DT, 128, 128, false>(d1, d2, d2, st);
-        case 160: return c64 ? launch_tail<DT, 160, 64, false>(d1, d2, d2, st) : launch_tail<DT, 160, 128, false>(d1, d2, d2, st);
+        case 128: return c64 ? launch_tail<DT, 128, 64>(d1, d2, st) : launch_tail<DT, 128, 128>(d1, d2, st);
+        case 160: return c64 ? launch_tail<DT, 160, 64>(d1, d2, st) : launch_tail<DT, 160, 128>(d1, d2, st);
         default: return GPP_ERR_BAD_ARG;
     }
 }

@@ -31,6 +31,24 @@
 
 #include "gpp.h"
 
+// This file is compiled WITHOUT packed-FP32 instructions (Makefile: NOPK).  Round 3 found that on this platform a wavefront that is
+// context-saved and resumed (compute wave save / restore: the driver rebuilds the runlist whenever ANY process on the GPU creates or
+// destroys a queue) can lose the lanes 48-63 of a v_pk_{mul,add,fma}_f32 result: with the packed build 87 of 32 000 plan runs under
+// queue churn returned a wrong plane (the one-lane-state dump showed a uniform poll target reading 0 in exactly those 16 lanes of one
+// wavefront), with the unpacked build 0 of 32 000 on the same box (tools/poll_race_stress.py, DESIGN.md section 4.4, profiles/r3/).
+//
+// Diagnostic build only (make polldbg -> libgpp_hip_polldbg.so, tools/poll_race_stress.py): the kernel additionally stores every
+// lane's state after its scan (8 words per lane).  The production library contains none of it.
+#ifdef GPP_POLL_DEBUG
+static float* g_poll_dbg = nullptr;
+extern "C" int gpp_poll_debug_buffer(void* buf) { g_poll_dbg = (float*)buf; return GPP_OK; }
+#define GPP_POLL_DBG_PARAM , float* __restrict__ dbg
+#define GPP_POLL_DBG_ARG , g_poll_dbg
+#else
+#define GPP_POLL_DBG_PARAM
+#define GPP_POLL_DBG_ARG
+#endif
+
 namespace {
 
 constexpr int kWaves = 4;
@@ -96,7 +114,7 @@ __global__ __launch_bounds__(kThreads) void poll_kernel(
     const float* __restrict__ boxes, const float* __restrict__ dims, const int32_t* __restrict__ orient,
     const float* __restrict__ P_inv, const float4* __restrict__ canon, int D, int N, int planes_batched, float thr,
     float* __restrict__ keypoints, float* __restrict__ keyplanes, float* __restrict__ residuals,
-    int32_t* __restrict__ best_idx)
+    int32_t* __restrict__ best_idx GPP_POLL_DBG_PARAM)
 {
     const int det = blockIdx.x;           // one workgroup per (image, detection)
     const int b = det / D;
@@ -146,7 +164,13 @@ __global__ __launch_bounds__(kThreads) void poll_kernel(
             if (key < rmin) { rmin = key; imin = j; }
         }
     };
+#ifdef GPP_POLL_DEBUG
+    int dbg_iters = 0;
+#endif
     for (int j = tid; j < N; j += UNROLL * kThreads) {
+#ifdef GPP_POLL_DEBUG
+        ++dbg_iters;
+#endif
         Hyp hy[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -158,6 +182,15 @@ __global__ __launch_bounds__(kThreads) void poll_kernel(
             if (j + u * kThreads < N) update(hy[u], j + u * kThreads);
     }
 
+#ifdef GPP_POLL_DEBUG
+    if (dbg) {      // every lane's state after its scan (8 words per lane): rmin, imin, i100, level, active-lane mask (lo, hi), iterations, tid
+        float* q = dbg + ((size_t)det * kThreads + tid) * 8;
+        const unsigned long long act = __ballot(1);
+        q[0] = rmin; q[1] = __int_as_float(imin); q[2] = __int_as_float(i100); q[3] = __int_as_float(level);
+        q[4] = __int_as_float((int)(act & 0xffffffffu)); q[5] = __int_as_float((int)(act >> 32)); q[6] = __int_as_float(dbg_iters);
+        q[7] = __int_as_float(tid);
+    }
+#endif
     // ---- merge: agree on the maximum level, demote lanes below it
     int vmax = level;
 #pragma unroll
@@ -248,13 +281,13 @@ extern "C" int gpp_poll_f32(const float* boxes, const float* dims, const int32_t
     const int u = unroll ? unroll : (N >= 16 * kThreads ? 4 : (N >= 4 * kThreads ? 2 : 1));
     if (u >= 4)
         poll_kernel<4><<<dim3((unsigned)(B * D)), dim3(kThreads), 0, st>>>(boxes, dims, orient, P_inv, (const float4*)workspace, D, N,
-                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx);
+                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx GPP_POLL_DBG_ARG);
     else if (u >= 2)
         poll_kernel<2><<<dim3((unsigned)(B * D)), dim3(kThreads), 0, st>>>(boxes, dims, orient, P_inv, (const float4*)workspace, D, N,
-                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx);
+                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx GPP_POLL_DBG_ARG);
     else
         poll_kernel<1><<<dim3((unsigned)(B * D)), dim3(kThreads), 0, st>>>(boxes, dims, orient, P_inv, (const float4*)workspace, D, N,
-                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx);
+                                                                             planes_batched, thr, keypoints, keyplanes, residuals, best_idx GPP_POLL_DBG_ARG);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }

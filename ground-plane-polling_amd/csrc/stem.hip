@@ -603,7 +603,7 @@ extern "C" int gpp_relu_strided(const void* in, int64_t in_bstride, void* out, i
     const int64_t n8 = count / 8;
     const dim3 grid((unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GPP_BF16X3) {                  // a pre-split map: float32-sized elements, whole 32-channel blocks
+    if (dtype == GPP_BF16X3 || dtype == GPP_F16X3) {      // a pre-split map (the sign bit of a half sits in the same place for both types)
         if (count % 32 != 0 || in_bstride % 32 != 0 || out_bstride % 32 != 0) return GPP_ERR_BAD_ARG;
         relu_x3_kernel<<<grid, 256, 0, st>>>((const char*)in, in_bstride * 4, (char*)out, out_bstride * 4, count / 8);
         return result();

@@ -37,6 +37,7 @@ GPP_BF16 = 1
 GPP_F16 = 2
 GPP_F32 = 3
 GPP_BF16X3 = 4
+GPP_F16X3 = 5
 GPP_MAX_GROUPS = 5
 
 
@@ -67,7 +68,7 @@ class ConvDesc(ctypes.Structure):
                 ('in_bytes', ctypes.c_int32), ('weight_bytes', ctypes.c_int32),
                 ('partial', c_void_p), ('partial_bytes', c_int64), ('split_k', ctypes.c_int32), ('partial_rows', ctypes.c_int32),
                 ('groups', ConvGroup * GPP_MAX_GROUPS),
-                ('x3_split', ctypes.c_int32), ('reserved2', ctypes.c_int32)]
+                ('x3_split', ctypes.c_int32), ('reserved2', ctypes.c_int32), ('out_scale', c_void_p)]
 
 
 def _declare(lib):
@@ -121,6 +122,8 @@ def _declare(lib):
     lib.gpp_event_destroy.argtypes = [c_void_p]
     lib.gpp_event_elapsed_ms.restype = c_int
     lib.gpp_event_elapsed_ms.argtypes = [c_void_p, c_void_p, ctypes.POINTER(c_float)]
+    lib.gpp_conv2d_tile_candidates.restype = c_int
+    lib.gpp_conv2d_tile_candidates.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int)]
     lib.gpp_conv2d_autotune.restype = c_int
     lib.gpp_conv2d_autotune.argtypes = [ctypes.POINTER(ConvDesc), c_int, c_void_p, ctypes.POINTER(c_float)]
 

@@ -17,21 +17,30 @@ from ..backend import hip
 
 def torch_dtype(dtype):
     import torch
-    return {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'bf16x3': torch.float32}[dtype]
+    return {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'bf16x3': torch.float32, 'f16x3': torch.float32}[dtype]
 
 
 def gpp_dtype(dtype):
     """ element / arithmetic type of the convolution kernels (include/gpp.h) """
-    return {'bf16': hip.GPP_BF16, 'f16': hip.GPP_F16, 'f32': hip.GPP_F32, 'bf16x3': hip.GPP_BF16X3}[dtype]
+    return {'bf16': hip.GPP_BF16, 'f16': hip.GPP_F16, 'f32': hip.GPP_F32, 'bf16x3': hip.GPP_BF16X3, 'f16x3': hip.GPP_F16X3}[dtype]
 
 
 def gpp_storage_dtype(dtype):
-    """ what the stem / pool / ReLU kernels see: 'bf16x3' stores float32 and only multiplies differently """
-    return hip.GPP_F32 if dtype in ('f32', 'bf16x3') else gpp_dtype(dtype)
+    """ what the stem / pool / ReLU kernels see: 'bf16x3' / 'f16x3' store float32 and only multiply differently """
+    return hip.GPP_F32 if dtype in ('f32', 'bf16x3', 'f16x3') else gpp_dtype(dtype)
+
+
+X3_TYPES = ('bf16x3', 'f16x3')       # float32 storage, three 16-bit matrix products per float32 product (include/gpp.h)
+
+
+def x3_half(dtype):
+    """ torch type of the two halves a value is split into """
+    import torch
+    return {'bf16x3': torch.bfloat16, 'f16x3': torch.float16}[dtype]
 
 
 def elem_size(dtype):
-    return 4 if dtype in ('f32', 'bf16x3') else 2
+    return 4 if dtype in ('f32', 'bf16x3', 'f16x3') else 2
 
 
 def k_chunk(dtype):
@@ -43,7 +52,7 @@ class FMap(object):
     """ A feature map living inside a torch buffer: pixel (b, y, x) starts at element
     off + b*bstride + (y*W + x)*pitch and has C contiguous channels. """
 
-    def __init__(self, buf, B, H, W, C, off=0, bstride=None, pitch=None, split=False):
+    def __init__(self, buf, B, H, W, C, off=0, bstride=None, pitch=None, split=False, half='bf16x3'):
         self.buf, self.B, self.H, self.W, self.C = buf, int(B), int(H), int(W), int(C)
         self.off = int(off)
         self.pitch = int(C if pitch is None else pitch)
@@ -51,16 +60,24 @@ class FMap(object):
         # dtype='bf16x3' only: a PRE-SPLIT map -- every 32 channels of a pixel (128 bytes of the float32-typed buffer) hold
         # [32 bf16 hi | 32 bf16 lo], hi = bf16(x), lo = bf16(x - hi), instead of 32 float32 (gpp_conv_desc.x3_split)
         self.split = bool(split)
+        self.half = half               # which of the two split types the halves are ('bf16x3' | 'f16x3'); only read when split
         if self.split:
             assert self.C % 32 == 0 and self.pitch % 32 == 0 and self.off % 32 == 0 and self.bstride % 32 == 0
 
+    def mark_split(self):
+        """ declare the map pre-split (same checks as the constructor's) """
+        assert self.C % 32 == 0 and self.pitch % 32 == 0 and self.off % 32 == 0 and self.bstride % 32 == 0
+        self.split = True
+        return self
+
     @classmethod
-    def empty(cls, B, H, W, C, dtype, device):
+    def empty(cls, B, H, W, C, dtype, device, split=False, half='bf16x3'):
         import torch
-        return cls(torch.empty((B, H, W, C), dtype=dtype, device=device), B, H, W, C)
+        return cls(torch.empty((B, H, W, C), dtype=dtype, device=device), B, H, W, C, split=split, half=half)
 
     def dense(self):
-        """ (B, H, W, C) torch view of the map (needs pitch*W*H <= bstride); raw storage -- for a pre-split map use read / write. """
+        """ (B, H, W, C) torch view of the map (needs pitch*W*H <= bstride); raw storage -- for a pre-split map these are the
+        [hi | lo] bits, not values: use read / write there. """
         import torch
         return torch.as_strided(self.buf.view(-1), (self.B, self.H, self.W, self.C),
                                 (self.bstride, self.W * self.pitch, self.pitch, 1), self.off)
@@ -70,7 +87,7 @@ class FMap(object):
         import torch
         if not self.split:
             return self.dense()
-        raw = self.dense().contiguous().view(torch.bfloat16).reshape(self.B, self.H, self.W, self.C // 32, 2, 32).float()
+        raw = self.dense().contiguous().view(x3_half(self.half)).reshape(self.B, self.H, self.W, self.C // 32, 2, 32).float()
         return (raw[..., 0, :] + raw[..., 1, :]).reshape(self.B, self.H, self.W, self.C)
 
     def write(self, values):
@@ -80,8 +97,10 @@ class FMap(object):
             self.dense().copy_(values.to(self.buf.dtype))
             return
         v = values.to(device=self.buf.device, dtype=torch.float32).reshape(self.B, self.H, self.W, self.C // 32, 32)
-        hi = v.to(torch.bfloat16)
-        lo = (v - hi.float()).to(torch.bfloat16)
+        if self.half == 'f16x3':
+            v = v.clamp(-65504.0, 65504.0)
+        hi = v.to(x3_half(self.half))
+        lo = (v - hi.float()).to(x3_half(self.half))
         both = torch.stack([hi, lo], dim=4).reshape(self.B, self.H, self.W, 2 * self.C)            # [.., chunk, (hi | lo), 32]
         self.dense().copy_(both.contiguous().view(torch.float32).reshape(self.B, self.H, self.W, self.C))
 
@@ -99,14 +118,39 @@ def pack_weight(kernel_hwio, dtype, device):
     # K order (chunk of CK input channels, kh, kw, CK channels): see include/gpp.h
     w[:Cout] = k.permute(3, 0, 1, 2).reshape(Cout, KH * KW, Cin // ck, ck).permute(0, 2, 1, 3).reshape(Cout, KH * KW * Cin)
     w = w[weight_row_order(rows)]
-    if dtype == 'bf16x3':
-        # every K-step of 32 channels becomes [32 bf16 hi | 32 bf16 lo], hi = bf16(w), lo = bf16(w - hi), both round-to-nearest:
+    if dtype in X3_TYPES:
+        # every K-step of 32 channels becomes [32 halves hi | 32 halves lo], hi = h(w), lo = h(w - hi), both round-to-nearest:
         # the same 128 bytes per row and K-step as float32, handed out as a float32-typed tensor of the usual shape
-        hi = w.to(torch.bfloat16)
-        lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+        if dtype == 'f16x3':
+            w = w * weight_scale(k, rows)[weight_row_order(rows)][:, None]          # exact: powers of two
+        hi = w.to(x3_half(dtype))
+        lo = (w - hi.to(torch.float32)).to(x3_half(dtype))
         both = torch.stack([hi.reshape(rows, -1, 32), lo.reshape(rows, -1, 32)], dim=2).reshape(rows, 2 * KH * KW * Cin)
         return both.contiguous().view(torch.float32).to(device).contiguous()
     return w.to(torch_dtype(dtype)).to(device).contiguous()
+
+
+def weight_scale(kernel_hwio, rows=None):
+    """ 'f16x3': the power of two every output channel's weights are multiplied by before they are split into two IEEE halves,
+    chosen so that the channel's largest weight lands in [2^13, 2^14) -- far from the half overflow (65504) and high enough that
+    the lo half of any weight down to 2^-13 of the largest is still a NORMAL half (a subnormal lo would carry fewer than 11 bits).
+    (C_out,) float32, or (rows,) padded with ones.  Its inverse is gpp_conv_desc.out_scale (out_scale_of). """
+    import torch
+    k = torch.as_tensor(np.ascontiguousarray(kernel_hwio, dtype=np.float32))
+    Cout = k.shape[3]
+    amax = k.abs().reshape(-1, Cout).max(dim=0).values.double()
+    e = torch.where(amax > 0, 13.0 - torch.floor(torch.log2(amax.clamp_min(1e-300))), torch.zeros_like(amax)).clamp(-100, 100)
+    scale = torch.pow(torch.tensor(2.0, dtype=torch.float64), e).float()
+    if rows is None:
+        return scale
+    out = torch.ones((rows,), dtype=torch.float32)
+    out[:Cout] = scale
+    return out
+
+
+def out_scale_of(kernel_hwio, device):
+    """ gpp_conv_desc.out_scale of a layer packed with pack_weight(..., 'f16x3'): 1 / weight_scale, exact """
+    return (1.0 / weight_scale(kernel_hwio)).to(device).contiguous()
 
 
 def weight_row_order(rows):
@@ -140,7 +184,7 @@ def same_pad(in_size, k, stride):
 
 def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=(0, 0), relu=False,
               residuals=None, dtype='bf16', out_f32=False, tile_hint=0, diag=0,
-              workspace=None, split_k=0):
+              workspace=None, split_k=0, out_scale=None):
     """ Build a gpp_conv_desc.  inputs / outputs / residuals are lists of FMap (one per group,
     all groups share weights; every list member must live in the same torch buffer). """
     d = hip.ConvDesc()
@@ -167,7 +211,10 @@ def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=
         d.partial_bytes = workspace.numel() * workspace.element_size()
     d.split_k = int(split_k)
     d.x3_split = (1 if inputs[0].split else 0) | (2 if outputs[0].split else 0) | (4 if (residuals and residuals[0].split) else 0)
-    assert d.x3_split == 0 or dtype == 'bf16x3'
+    assert d.x3_split == 0 or dtype in X3_TYPES
+    assert all(f.half == dtype for f in list(inputs) + list(outputs) + list(residuals or []) if f.split)
+    assert (out_scale is not None) == (dtype == 'f16x3'), 'f16x3 layers carry the inverse of their weight scale (out_scale_of)'
+    d.out_scale = out_scale.data_ptr() if out_scale is not None else None
     assert all(f.split == inputs[0].split for f in inputs) and all(f.split == outputs[0].split for f in outputs)
     assert 1 <= len(inputs) <= hip.GPP_MAX_GROUPS and len(outputs) == len(inputs)
     assert int(weight.shape[1]) == KH * KW * C_in

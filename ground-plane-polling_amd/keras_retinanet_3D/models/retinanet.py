@@ -80,14 +80,8 @@ class TailDesc(ctypes.Structure):
     _fields_ = [('conv3x3', ctypes.c_void_p), ('conv1x1', ctypes.c_void_p), ('tile_rows', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
-class TailNextDesc(ctypes.Structure):
-    _fields_ = [('conv3x3', ctypes.c_void_p), ('conv1x1', ctypes.c_void_p), ('next1x1', ctypes.c_void_p),
-                ('tile_rows', ctypes.c_int32), ('reserved', ctypes.c_int32)]
-
-
 OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4, 5, 6, 7
 OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT = 8, 9, 10
-OP_TAIL_NEXT = 11
 OP_DETECT_OSF = 12
 OP_STEM_POOL = 13
 DETECT_OPS = (OP_DETECT, OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT, 12)
@@ -131,8 +125,8 @@ class RetinaNet3D(object):
         self.backbone_name = backbone_name.split('_')[0]
         if self.backbone_name not in W.BLOCKS:
             raise ValueError('Backbone (\'{}\') not in allowed backbones ({}).'.format(backbone_name, sorted(W.BLOCKS)))
-        if dtype not in ('bf16', 'f16', 'f32', 'bf16x3'):
-            raise ValueError("dtype must be 'bf16', 'f16', 'f32' or 'bf16x3', got {!r}".format(dtype))
+        if dtype not in ('bf16', 'f16', 'f32', 'bf16x3', 'f16x3'):
+            raise ValueError("dtype must be 'bf16', 'f16', 'f32', 'bf16x3' or 'f16x3', got {!r}".format(dtype))
         self.dtype = dtype
         self.esz = C.elem_size(dtype)
         self.tdtype = C.torch_dtype(dtype)
@@ -151,10 +145,13 @@ class RetinaNet3D(object):
         torch, dev = self.torch, self.device
         W.validate_weights(weights, self.backbone_name)
         self.conv_w = {}
+        self.conv_scale = {}
 
         def put(name, kernel, bias):
             self.conv_w[name] = (C.pack_weight(kernel, self.dtype, dev), torch.as_tensor(bias).to(dev).contiguous(),
                                  kernel.shape)
+            if self.dtype == 'f16x3':        # the inverse of the per-channel power of two the packed weights carry (layers/conv.py)
+                self.conv_scale[name] = C.out_scale_of(kernel, dev)
 
         for conv, bn, kh, kw, cin, cout, _ in W.backbone_layers(self.backbone_name):
             k, b = W.folded_conv(weights, conv, bn)
@@ -193,7 +190,7 @@ class RetinaNet3D(object):
         if pad is None:
             pad = (0, 0)
         d = C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
-                        residuals=residuals, dtype=self.dtype, out_f32=out_f32)
+                        residuals=residuals, dtype=self.dtype, out_f32=out_f32, out_scale=self.conv_scale.get(name))
         # split-K partial tiles: the workspace of this op's stream lane is allocated once every op is known (_build)
         plan.conv_descs.append((d, lane))
         plan.ws_need[lane] = max(plan.ws_need.get(lane, 0), C.workspace_bytes(d))
@@ -205,28 +202,16 @@ class RetinaNet3D(object):
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
-    def _tail(self, plan, nm, a, y, shortcut, nxt=None):
+    def _tail(self, plan, nm, a, y, shortcut):
         """ branch2b (3x3) + branch2c (1x1, + shortcut, ReLU) of one bottleneck as ONE launch
-        (gpp_bottleneck_tail): the intermediate map never reaches HBM.  Bit-identical to the two layers.
-        nxt = (name of the following identity block, its branch2a output map): that block's first 1x1 layer is computed
-        by the same launch from the y tile while it is being stored (gpp_bottleneck_tail_next), bit-identical too. """
+        (gpp_bottleneck_tail): the intermediate map never reaches HBM.  Bit-identical to the two layers. """
         d1 = self._desc(plan, 'res{}_branch2b'.format(nm), [a], [a], 3, pad=(1, 1), relu=True)       # its `out` is never written
         d2 = self._desc(plan, 'res{}_branch2c'.format(nm), [a], [y], 1, relu=True, residuals=[shortcut])
         plan.keep += [d1, d2]
-        if nxt is None:
-            t = TailDesc(ctypes.addressof(d1), ctypes.addressof(d2), 0, 0)
-            name = 'res{}_branch2b+2c'.format(nm)
-            plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2))
-            plan.io[name] = ([a], [y], [shortcut])
-            return
-        nm_next, a_next = nxt
-        d3 = self._desc(plan, 'res{}_branch2a'.format(nm_next), [y], [a_next], 1, relu=True)
-        plan.keep.append(d3)
-        t = TailNextDesc(ctypes.addressof(d1), ctypes.addressof(d2), ctypes.addressof(d3), 0, 0)
-        name = 'res{}_branch2b+2c+res{}_branch2a'.format(nm, nm_next)
-        plan.add(OP_TAIL_NEXT, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2) + C.conv_flops(d3))
-        plan.io[name] = ([a], [y, a_next], [shortcut])
-        plan.oracle_names[name] = ['res{}_branch2c'.format(nm), 'res{}_branch2a'.format(nm_next)]
+        t = TailDesc(ctypes.addressof(d1), ctypes.addressof(d2), 0, 0)
+        name = 'res{}_branch2b+2c'.format(nm)
+        plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2))
+        plan.io[name] = ([a], [y], [shortcut])
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
         torch, dev, dt = self.torch, self.device, self.tdtype
@@ -238,18 +223,17 @@ class RetinaNet3D(object):
         plan.conv_descs, plan.ws_need = [], {}
 
         def fmap(h, w, c, dtype=None):
-            f = C.FMap.empty(B, h, w, c, dtype or dt, dev)
+            f = C.FMap.empty(B, h, w, c, dtype or dt, dev, half=self.dtype if self.dtype in C.X3_TYPES else 'bf16x3')
             plan.keep.append(f.buf)
             return f
 
         # dtype='bf16x3': maps written and read by convolutions only are stored PRE-SPLIT ([32 bf16 hi | 32 bf16 lo] per 32 channels,
         # gpp_conv_desc.x3_split): GPP_X3_SPLIT=2 (default) every such map, 1 = only the maps between the FPN / head layers, 0 = none
-        x3_level = int(os.environ.get('GPP_X3_SPLIT', '2')) if self.dtype == 'bf16x3' else 0
+        x3_level = int(os.environ.get('GPP_X3_SPLIT', '2')) if self.dtype in C.X3_TYPES else 0
 
         def bmap(h, w, c):
             f = fmap(h, w, c)
-            f.split = x3_level >= 2
-            return f
+            return f.mark_split() if x3_level >= 2 else f
 
         # ---- inputs
         plan.images = torch.empty((B, H, Wd, 3), dtype=torch.float32, device=dev)
@@ -288,14 +272,8 @@ class RetinaNet3D(object):
         if self.esz == 4:
             fuse_tail = []              # the fused tail keeps a 16-bit intermediate tile in LDS: 16-bit storage types only
 
-        # GPP_FUSE_NEXT=1: additionally the first 1x1 layer of the FOLLOWING identity block in the same launch
-        # (gpp_bottleneck_tail_next: y feeds the next product from registers, bit-identical).  Off by default -- measured
-        # slower than the separate launch (C = 64: 137 us vs 92 + 36; C = 128: 151 vs 55 + 24): every wavefront re-reads all
-        # of W3 from L2 and the 250-register kernel drops to two workgroups per CU (tools/bench_conv.py stamps_tail)
-        fuse_next = os.environ.get('GPP_FUSE_NEXT', '0') != '0'
-
         def sub(fm, c0, nb):
-            return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch, split=fm.split)
+            return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch, split=fm.split, half=fm.half)
 
         feats = []
         for stage, n_blocks in enumerate(W.BLOCKS[self.backbone_name]):
@@ -315,24 +293,17 @@ class RetinaNet3D(object):
             for c0 in range(0, B, chunk):
                 nb = min(chunk, B - c0)
                 xs = sub(xin, c0, nb)
-                have_2a = False                  # branch2a of this block already computed by the previous block's launch
-                for bi, rec in enumerate(blocks):
+                for rec in blocks:
                     nm, stride = rec['nm'], rec['stride']
                     a_, y_ = sub(rec['a'], c0, nb), sub(rec['y'], c0, nb)
-                    if not have_2a:
-                        self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True)
-                    have_2a = False
+                    self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True)
                     if rec['sc'] is not None:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride)
                     else:
                         sc_ = xs
                     if rec['b'] is None:
-                        nxt = None
-                        if fuse_next and bi + 1 < len(blocks) and blocks[bi + 1]['b'] is None:
-                            nxt = (blocks[bi + 1]['nm'], sub(blocks[bi + 1]['a'], c0, nb))
-                            have_2a = True
-                        self._tail(plan, nm, a_, y_, sc_, nxt)
+                        self._tail(plan, nm, a_, y_, sc_)
                     else:
                         b_ = sub(rec['b'], c0, nb)
                         self._conv(plan, 'res{}_branch2b'.format(nm), [a_], [b_], 3, pad=(1, 1), relu=True)
@@ -361,12 +332,12 @@ class RetinaNet3D(object):
             buf = torch.empty((B, total, c), dtype=dtype or dt, device=dev)
             plan.keep.append(buf)
             sp = x3s and dtype is None
-            return buf, [C.FMap(buf, B, shapes[i][0], shapes[i][1], c, off=lvl_off[i] * c, bstride=total * c, split=sp) for i in range(5)]
+            return buf, [C.FMap(buf, B, shapes[i][0], shapes[i][1], c, off=lvl_off[i] * c, bstride=total * c, split=sp,
+                                half=self.dtype if sp else 'bf16x3') for i in range(5)]
 
         def smap(h, w, c):
             f = fmap(h, w, c)
-            f.split = x3s
-            return f
+            return f.mark_split() if x3s else f
 
         pyr, P = pyramid(512)
         T5 = smap(C5.H, C5.W, 512)
@@ -378,7 +349,7 @@ class RetinaNet3D(object):
         self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]), lane=l_p6)
         R6 = smap(shapes[3][0], shapes[3][1], 512)
         plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * self.esz, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
-                                   pix[3] * 512, hip.GPP_BF16X3 if x3s else C.gpp_storage_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
+                                   pix[3] * 512, C.gpp_dtype(self.dtype) if x3s else C.gpp_storage_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
         plan.relu_io = (P[3], R6)
         self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
                    pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]), lane=l_p6)
@@ -396,7 +367,7 @@ class RetinaNet3D(object):
         # tensor; layers 1..3 read their channel slice of it (in_pitch > C_in)
         wide, wide_maps = pyramid(896)
         def slice_of(maps, c0, c):
-            return [C.FMap(m.buf, B, m.H, m.W, c, off=m.off + c0, bstride=m.bstride, pitch=m.pitch, split=m.split) for m in maps]
+            return [C.FMap(m.buf, B, m.H, m.W, c, off=m.off + c0, bstride=m.bstride, pitch=m.pitch, split=m.split, half=m.half) for m in maps]
 
         # (measured and rejected: the half-empty fourth 256-column tile of this 896-wide layer as its own 128-column launch
         # on a side stream -- the two launches do not pack into each other's partial rounds, no gain)
@@ -550,16 +521,37 @@ class RetinaNet3D(object):
         best = ctypes.c_float(0.0)
         fresh = False
         plan.tuning = {}
+        # GPP_TUNE_RANDOM=<seed> (tests / tools/first_run_stress.py): every layer takes a RANDOM tile among those the library
+        # accepts for it instead of the fastest one -- the outputs may not change by a bit, whatever the draw
+        rnd = None
+        if os.environ.get('GPP_TUNE_RANDOM'):
+            import random
+            rnd = random.Random(int(os.environ['GPP_TUNE_RANDOM']) * 1000003 + int(os.environ.get('RANK', '0')))
         for index, (kind, _, desc, name, flops) in enumerate(plan.ops):
             if kind in DETECT_OPS or kind == OP_POLL:
                 continue
             self.run_op(plan, index)
-            if kind in (OP_TAIL, OP_TAIL_NEXT):
+            if rnd is not None and kind in (OP_TAIL, OP_CONV):
+                if kind == OP_CONV:
+                    tiles, count = (ctypes.c_int * 32)(), ctypes.c_int(0)
+                    hip.check(hip.lib().gpp_conv2d_tile_candidates(ctypes.byref(desc), tiles, 32, ctypes.byref(count)), 'gpp_conv2d_tile_candidates')
+                    ok = []
+                    for tile in tiles[:count.value]:         # a candidate the launcher refuses for this shape is skipped, as the autotuner does
+                        desc.tile_hint = tile
+                        if hip.lib().gpp_plan_run(ctypes.byref(plan.array, index * ctypes.sizeof(PlanOp)), 1, hip.stream_ptr(), None, 0) == 0:
+                            ok.append(tile)
+                    desc.tile_hint = rnd.choice(ok)
+                    plan.tuning[name] = (int(desc.tile_hint), 0.0)
+                else:
+                    desc.tile_rows = rnd.choice((96, 128, 160))
+                    plan.tuning[name] = (int(desc.tile_rows), 0.0)
+                self.run_op(plan, index)
+                continue
+            if kind == OP_TAIL:
                 key = (name, B, H, Wd)
                 if key not in self._tuned:
                     times = {}
-                    c_mid = ctypes.cast(desc.conv3x3, ctypes.POINTER(hip.ConvDesc)).contents.C_in
-                    for rows in ((96, 128, 160) if kind == OP_TAIL else ((64, 128) if c_mid == 64 else (64,))):
+                    for rows in (96, 128, 160):
                         desc.tile_rows = rows
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         self.run_op(plan, index)

@@ -26,6 +26,17 @@ from . import gpp_utils
 
 RANGE_M = 100.0
 
+# BASELINE.json north_star: "bit-exact plane-index/argmax selection, 3D box corners within 1e-3" against the reference-precision
+# path on identical inputs.  A throughput mode may be quoted as the BASELINE metric only when its ledger against the float32 path
+# meets all three (bench.py enforces it for its headline type, tests/test_fullsize_gpu.py for 'f16x3').
+REFERENCE_BARS = {'detection_set_agreement': 1.0, 'plane_index_agreement': 1.0, 'max_corner_dev_m_within_100m': 1e-3}
+
+
+def meets_reference_bars(led):
+    """ the same detections, the same plane for every one of them, 3-D corners within 1e-3 m """
+    return bool(led['detection_set_agreement'] == 1.0 and led['plane_index_agreement'] == 1.0 and
+                led['orientation_agreement'] == 1.0 and led['max_corner_dev_m_within_100m'] <= 1e-3)
+
 
 def _dev(a, b):
     """ |a - b| element-wise in float64; a non-finite value (a degenerate pose of a random-weight detection) counts as

@@ -80,6 +80,12 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
                         (float32: 2^-24, plain bf16 operands: 2^-8) at a third of the bf16 MFMA rate.  Activations, residuals
                         and outputs are float32 exactly as for GPP_F32; the weight matrix holds, per K-step of 32 input
                         channels, the 32 bf16 hi parts followed by the 32 bf16 lo parts (same bytes per row as float32). */
+#define GPP_F16X3 5  /* as GPP_BF16X3 with IEEE-half halves: hi = f16(x), lo = f16(x - hi), 11 + 11 significant bits, ~2^-22 relative
+                        error per product (float32: 2^-24): the throughput mode that stays inside the reference-precision tolerance
+                        (plane index exact, 3-D corners within 1e-3 of the float32 path).  Range: activations beyond +-65504 are
+                        clamped when they are split; the packed weights of an output channel are scaled by a power of two so that
+                        both halves are normal halfs, and gpp_conv_desc.out_scale (float32 per output channel, the inverse power of
+                        two) is applied to the accumulator before the bias. */
 
 /* ------------------------------------------------------------------------------------------
  * 2-D convolution, NHWC, implicit GEMM on MFMA (no im2col buffer), fused epilogue
@@ -135,7 +141,7 @@ typedef struct gpp_conv_desc {
     const void* residual;
     void* out;
     const void* zero_page;
-    int32_t dtype;                  /* GPP_BF16 | GPP_F16 | GPP_F32 | GPP_BF16X3 */
+    int32_t dtype;                  /* GPP_BF16 | GPP_F16 | GPP_F32 | GPP_BF16X3 | GPP_F16X3 */
     int32_t out_f32;
     int32_t batch, C_in, C_out, KH, KW, stride, pad_top, pad_left;
     int32_t in_pitch, out_pitch, res_pitch;   /* elements per pixel */
@@ -159,7 +165,7 @@ typedef struct gpp_conv_desc {
     int32_t split_k;                /* 0 = gpp_conv2d_split_rule (a function of the layer alone), 1 = never, k > 1 = exactly k */
     int32_t partial_rows;           /* filled in by the library */
     gpp_conv_group groups[GPP_MAX_GROUPS];
-    int32_t x3_split;               /* GPP_BF16X3 only (0 otherwise): which of the float32-sized maps hold PRE-SPLIT values, bits
+    int32_t x3_split;               /* GPP_BF16X3 / GPP_F16X3 only (0 otherwise): which of the float32-sized maps hold PRE-SPLIT values, bits
                                        GPP_X3_IN | GPP_X3_OUT | GPP_X3_RES.  A pre-split map stores every 32 channels of a pixel
                                        (128 bytes) as [32 bf16 hi | 32 bf16 lo], hi = bf16(x), lo = bf16(x - hi) -- the layout the
                                        packed weights already have -- instead of 32 float32: the matrix loop then takes its
@@ -167,6 +173,8 @@ typedef struct gpp_conv_desc {
                                        issue slots with the matrix pipe.  Needs pitches and offsets that are multiples of 32
                                        channels; an output map can be pre-split only when out_f32 == 0 and C_out % 32 == 0 */
     int32_t reserved2;              /* must be 0 */
+    const float* out_scale;         /* GPP_F16X3 only (NULL otherwise, and NULL = all ones): per output channel, accumulator *= out_scale[n]
+                                       before the bias -- the inverse of the power of two the channel's packed weights were scaled by */
 } gpp_conv_desc;
 #define GPP_X3_IN 1
 #define GPP_X3_OUT 2
@@ -187,19 +195,16 @@ int gpp_conv2d_workspace_bytes(const gpp_conv_desc* host_desc, size_t* bytes);
    Results do not depend on the tile (same K order per output element); split_k is used as given, never tuned. */
 int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* best_us);
 
+/* The tile codes gpp_conv2d_autotune would time for this layer (count = how many there are; the first min(count, capacity)
+   are written to tiles).  Any of them gives the same bytes; tests draw from this list at random (GPP_TUNE_RANDOM). */
+int gpp_conv2d_tile_candidates(const gpp_conv_desc* host_desc, int* tiles, int capacity, int* count);
+
 /* Fused tail of a ResNet bottleneck (keras_resnet bottleneck_2d, used at /root/reference/keras_retinanet_3D/models/
    resnet.py:88-93): the 3x3 conv "branch2b" (C -> C, C = 64 or 128, stride 1, pad 1, + bias + ReLU) and the 1x1 conv
    "branch2c" (C -> multiple of 128, + bias + residual + ReLU) in ONE launch; the intermediate map stays in LDS.
    conv3x3->out is not written.  Results are bit-identical to gpp_conv2d_igemm(conv3x3) + gpp_conv2d_igemm(conv1x1).
    tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup.  Other shapes, and GPP_F32: GPP_ERR_UNSUPPORTED. */
 int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream);
-
-/* The same launch extended by the FIRST layer of the following identity bottleneck ("branch2a": 1x1, 4C -> C, + bias +
-   ReLU): next1x1->in must be the map conv1x1 writes.  The rounded y tile feeds the next matrix product straight from the
-   registers it is stored from; next1x1->out is bit-identical to gpp_conv2d_igemm(next1x1) run after the two-layer launch.
-   tile_rows: 0 (= 128), 64 or 128. */
-int gpp_bottleneck_tail_next(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, const gpp_conv_desc* next1x1,
-                             int tile_rows, void* stream);
 
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
@@ -331,7 +336,7 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 #define GPP_OP_DETECT_CANDIDATES 8   /* gpp_detect_desc; stages of GPP_OP_DETECT, see gpp_detect_stages_f32 */
 #define GPP_OP_DETECT_SELECT 9
 #define GPP_OP_DETECT_EMIT 10
-#define GPP_OP_BOTTLENECK_TAIL_NEXT 11   /* gpp_tail_next_desc */
+/* (11: the three-layer tail of round 2, removed in round 3 -- measured slower than its separate launches) */
 #define GPP_OP_DETECT_OSF 12             /* gpp_detect_desc -> gpp_detect_osf_f32 */
 #define GPP_OP_STEM_POOL 13              /* gpp_stem_desc with out = the pooled map -> gpp_stem_pool_fused_mfma */
 /* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
@@ -365,8 +370,6 @@ typedef struct gpp_poll_desc {
 } gpp_poll_desc;
 
 typedef struct gpp_tail_desc { const gpp_conv_desc* conv3x3; const gpp_conv_desc* conv1x1; int32_t tile_rows, reserved; } gpp_tail_desc;
-typedef struct gpp_tail_next_desc { const gpp_conv_desc* conv3x3; const gpp_conv_desc* conv1x1; const gpp_conv_desc* next1x1;
-                                    int32_t tile_rows, reserved; } gpp_tail_next_desc;
 
 typedef struct gpp_plan_op { int32_t kind; int32_t tag; const void* desc; } gpp_plan_op;
 

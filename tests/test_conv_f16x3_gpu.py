@@ -1,0 +1,279 @@
+"""
+GPU numerics of GPP_F16X3: float32 storage, every float32 product as three IEEE-half matrix products (x = hi + lo, hi = f16(x),
+lo = f16(x - hi): 11 + 11 significant bits per operand, the lo * lo term dropped: ~2^-22 per product; float32: 2^-24).  This is
+the throughput mode that has to stay inside the reference-precision tolerance of BASELINE.json (plane index exact, 3-D corners
+within 1e-3 of the float32 path), so its bars are float32's:
+
+    |err| <= 1e-5 |ref| + 2e-6 rms(ref) sqrt(K)  per element  (the bar of tests/test_conv_f32_gpu.py for GPP_F32), and
+    rms(err) <= (3e-8 sqrt(K) + 1e-7) rms(ref)                (measured 1.0e-7 at K = 64 ... 1.0e-6 at K = 9216,
+                                                               tools/x3_error_probe.py; GPP_BF16X3 sits at 4e-6 throughout)
+
+against a float64 reference of the same op on the values the operands hold.  Also: the range handling (activations clamped at
++-65504, per-output-channel power-of-two weight scale + gpp_conv_desc.out_scale, subnormal lo halves -- the matrix pipe keeps
+half subnormals, tools/micro/mfma_denorm.hip), pre-split maps in every flag combination, tile / split-K invariance, the
+dual-shape grid, ReLU on a pre-split map, argument validation.
+"""
+import ctypes
+
+import pytest
+import torch
+
+from keras_retinanet_3D.backend import hip
+from keras_retinanet_3D.layers import conv as C
+from test_conv_gpu import CASES
+from test_conv_f32_gpu import reference64
+
+pytestmark = pytest.mark.gpu
+
+PLAIN_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128, 128160, 128256, 192256, 256256]
+PIPE_TILES = [1128128, 1192128, 1128256, 1192256, 1256256]
+
+
+def held(t):
+    """ what a pre-split GPP_F16X3 map holds of a value: hi + lo (about 22 significant bits, clamped to the half range) """
+    t = t.clamp(-65504.0, 65504.0)
+    hi = t.to(torch.float16).float()
+    return hi + (t - hi).to(torch.float16).float()
+
+
+def build(case, flags=0, seed_shift=0, x_scale=1.0, channel_spread=False):
+    """ one layer of tests/test_conv_gpu.CASES in GPP_F16X3; flags = which maps are pre-split (GPP_X3_IN | OUT | RES) """
+    name, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, _ = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + seed_shift)
+    dev = torch.device('cuda')
+    x = torch.randn((B, H, W, Cin), generator=g) * x_scale
+    k = torch.randn((K, K, Cin, Cout), generator=g) * (2.0 / (K * K * Cin)) ** 0.5
+    if channel_spread:                                    # output channels nine decades apart: the per-channel scale has to cope
+        k = k * torch.pow(10.0, torch.linspace(-6.0, 3.0, Cout))[None, None, None, :]
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    if pad is None:
+        oh, pt = C.same_pad(H, K, stride)
+        ow, pl = C.same_pad(W, K, stride)
+    else:
+        pt, pl = pad
+        oh, ow = out_hw if out_hw else (H, W)
+    res = None
+    if resmode == 'same':
+        res = torch.randn((B, oh, ow, Cout), generator=g)
+    elif resmode is not None:
+        res = torch.randn((B, resmode[0], resmode[1], Cout), generator=g)
+    if res is None:
+        flags &= 3
+    x_held = held(x) if flags & 1 else x.clamp(-65504.0, 65504.0)
+    res_held = None if res is None else (held(res) if flags & 4 else res)
+    ref = reference64(x_held, k, bias, stride, pt, pl, oh, ow, relu, res_held)
+    xin = C.FMap.empty(B, H, W, Cin, torch.float32, dev, split=bool(flags & 1), half='f16x3')
+    xin.write(x)
+    out = C.FMap.empty(B, oh, ow, Cout, torch.float32, dev, split=bool(flags & 2), half='f16x3')
+    rmap = None
+    if res is not None:
+        rm = C.FMap.empty(B, res.shape[1], res.shape[2], Cout, torch.float32, dev, split=bool(flags & 4), half='f16x3')
+        rm.write(res)
+        rmap = [rm]
+    w = C.pack_weight(k.numpy(), 'f16x3', dev)
+    scale = C.out_scale_of(k.numpy(), dev)
+    ws = torch.empty((32 << 20,), dtype=torch.uint8, device=dev)
+    bias_d = bias.to(dev)
+
+    def make(tile, split_k=1):
+        return C.conv_desc([xin], [out], w, bias_d, K, K, Cin, Cout, stride=stride, pad=(pt, pl), relu=relu, residuals=rmap,
+                           dtype='f16x3', tile_hint=tile, workspace=ws, split_k=split_k, out_scale=scale)
+    return make, out, ref, K * K * Cin, (xin, w, scale, rmap, ws, bias_d), flags
+
+
+def check(out, ref, kdepth, rms_factor=1.0):
+    got = out.read().double().cpu()
+    assert torch.isfinite(got).all()
+    rms = float(ref.pow(2).mean().sqrt())
+    err = (got - ref).abs()
+    tol = 1e-5 * ref.abs() + 2e-6 * rms * kdepth ** 0.5                      # float32's own bar
+    assert bool((err <= tol).all()), 'max err {} (rms {})'.format(err.max().item(), rms)
+    assert float(err.pow(2).mean().sqrt()) <= rms_factor * (3e-8 * kdepth ** 0.5 + 1e-7) * rms
+
+
+def fits(d, tile):
+    bn = tile % 1000 if tile else 64
+    return -(-d.C_out // bn) * bn <= d.weight_rows
+
+
+@pytest.mark.parametrize('tile', [0, 64064, 128128, 192128, 128160, 256256])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_f16x3_matches_float64_like_float32_does(case, tile):
+    make, out, ref, kdepth, _, _ = build(case)
+    out.buf.fill_(float('nan'))
+    d = make(tile)
+    if not fits(d, tile):
+        pytest.skip('tile grid would read past the packed weight rows')
+    C.run_conv(d)
+    check(out, ref, kdepth)
+
+
+@pytest.mark.parametrize('flags', [1, 2, 4, 3, 7])
+@pytest.mark.parametrize('tile', [0, 96128, 192128, 192160, 128256, 1256256, 1192128])
+@pytest.mark.parametrize('case', ['3x3_wide', '1x1_res_up_nonint', 'bottleneck_2c', '3x3_s2_tfsame', 'deepK'])
+def test_f16x3_pre_split_maps(case, tile, flags):
+    c = [c for c in CASES if c[0] == case][0]
+    if c[4] % 32 or ((flags & 6) and c[5] % 32):
+        pytest.skip('pre-split maps hold whole 32-channel blocks')
+    make, out, ref, kdepth, _, eff = build(c, flags=flags, seed_shift=flags)
+    out.buf.fill_(float('nan'))
+    d = make(tile, split_k=3 if case == 'deepK' else 1)
+    assert d.x3_split == eff
+    if not fits(d, tile):
+        pytest.skip('tile grid would read past the packed weight rows')
+    if (tile > 1000000 or tile == 192160) and not (eff & 1):
+        assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -4      # these forms read pre-split rows only
+        return
+    C.run_conv(d)
+    check(out, ref, kdepth, rms_factor=1.5 if eff & 2 else 1.0)                        # a pre-split OUTPUT is rounded to 22 bits once more
+
+
+@pytest.mark.parametrize('case', ['3x3_wide', 'bottleneck_2c', '3x3_s2_tfsame', 'deepK', '1x1'])
+def test_every_f16x3_tile_gives_identical_results(case):
+    """ plain, 8-wavefront and software-pipelined tiles, float32 and pre-split input maps, with and without split-K: an output
+    element is summed in the same order (hi * wlo, hi * whi, lo * whi per K-step) -> identical bits """
+    c = [c for c in CASES if c[0] == case][0]
+    for flags in (0, 7):
+        make, out, _, kdepth, _, eff = build(c, flags=flags)
+        nk = kdepth // 32
+        for split_k in (1, 3):
+            if nk < 4 * split_k:
+                continue
+            base = None
+            for tile in PLAIN_TILES + ([192160] + PIPE_TILES if eff & 1 else []):
+                d = make(tile, split_k=split_k)
+                if not fits(d, tile):
+                    continue
+                out.buf.fill_(float('nan'))
+                C.run_conv(d)
+                got = out.buf.clone()
+                assert torch.isfinite(out.read()).all()
+                if base is None:
+                    base = got
+                assert torch.equal(got.view(torch.int32), base.view(torch.int32)), (tile, split_k, flags)
+
+
+@pytest.mark.parametrize('cin,cout,relu', [(128, 384, True), (64, 896, True)])
+def test_f16x3_dual_shape_grid(cin, cout, relu):
+    """ tile code 2256256 (C_out = 256 k + 128, pre-split input): the bits of the plain tile over several ragged feature maps;
+    the out_scale pointer of the 128-column block is moved with its weights """
+    g = torch.Generator().manual_seed(cout)
+    dev = torch.device('cuda')
+    B, shapes = 2, [(21, 29), (11, 15), (6, 8), (3, 4)]
+    total = sum(h * w for h, w in shapes)
+    xbuf = torch.empty((B, total, cin), dtype=torch.float32, device=dev)
+    k = torch.randn((3, 3, cin, cout), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    k = k * torch.pow(2.0, torch.randint(-6, 7, (cout,), generator=g).float())[None, None, None, :]      # a different scale per channel
+    w = C.pack_weight(k.numpy(), 'f16x3', dev)
+    scale = C.out_scale_of(k.numpy(), dev)
+    b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    ins, off, xs = [], 0, []
+    for h, wd in shapes:
+        fm = C.FMap(xbuf, B, h, wd, cin, off=off * cin, bstride=total * cin, split=True, half='f16x3')
+        xs.append(torch.randn((B, h, wd, cin), generator=g))
+        fm.write(xs[-1])
+        ins.append(fm)
+        off += h * wd
+    results = []
+    for tile in (128128, 2256256):
+        o = torch.full((B, total, cout), float('nan'), dtype=torch.float32, device=dev)
+        outs, off = [], 0
+        for h, wd in shapes:
+            outs.append(C.FMap(o, B, h, wd, cout, off=off * cout, bstride=total * cout, split=True, half='f16x3'))
+            off += h * wd
+        C.run_conv(C.conv_desc(ins, outs, w, b, 3, 3, cin, cout, pad=(1, 1), relu=relu, dtype='f16x3', tile_hint=tile, out_scale=scale))
+        results.append(o.view(torch.int32).cpu())
+        for fm, x in zip(outs, xs):
+            ref = reference64(held(x), k, b.cpu(), 1, 1, 1, fm.H, fm.W, relu, None)
+            got = fm.read().double().cpu()
+            rms = float(ref.pow(2).mean().sqrt())
+            assert float((got - ref).pow(2).mean().sqrt()) <= 1.5 * (3e-8 * (9 * cin) ** 0.5 + 1e-7) * rms
+    assert torch.equal(results[0], results[1])
+
+
+def test_f16x3_range_activations_beyond_the_half_range_are_clamped_not_inf():
+    c = [c for c in CASES if c[0] == '3x3'][0]
+    for flags in (0, 1):
+        make, out, ref, kdepth, keep, _ = build(c, flags=flags, x_scale=1.0)
+        xin = keep[0]
+        x = xin.read().clone()
+        x[0, 3, 4, 5] = 1.0e6                              # -> 65504
+        x[1, 2, 2, 7] = -3.0e38                            # -> -65504
+        xin.write(x)
+        k_ref = reference64(x.cpu().clamp(-65504.0, 65504.0), *_case_tensors(c)[1:])
+        out.buf.fill_(float('nan'))
+        C.run_conv(make(128128))
+        got = out.read().double().cpu()
+        assert torch.isfinite(got).all()
+        rms = float(k_ref.pow(2).mean().sqrt())
+        assert float((got - k_ref).abs().max()) <= 1e-5 * float(k_ref.abs().max()) + 1e-5 * rms
+
+
+def _case_tensors(case):
+    """ the tensors build() draws for a case (same generator order), for references on modified inputs """
+    name, B, H, W, Cin, Cout, K, stride, pad, out_hw, relu, resmode, _ = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = torch.randn((B, H, W, Cin), generator=g)
+    k = torch.randn((K, K, Cin, Cout), generator=g) * (2.0 / (K * K * Cin)) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    pt, pl = pad
+    oh, ow = out_hw if out_hw else (H, W)
+    return x, k, bias, stride, pt, pl, oh, ow, relu, None
+
+
+@pytest.mark.parametrize('x_scale', [1e-2, 1e-4, 3e-6])
+def test_f16x3_tiny_activations_keep_their_low_half(x_scale):
+    """ |x| < 2^-3: lo = f16(x - hi) is a SUBNORMAL half (the matrix pipe keeps them); |x| < 6e-5: hi is subnormal too.  The absolute
+    error stays at the subnormal spacing 2^-24 per operand, so a map of tiny values loses RELATIVE precision only below ~1e-3:
+    bar rms(err) <= (2^-24 / x_scale + 3e-7) * sqrt(K) * rms(w) * x_scale-ish, stated as a fraction of rms(ref) """
+    c = [c for c in CASES if c[0] == '3x3_wide'][0]
+    for flags in (0, 1):
+        make, out, ref, kdepth, _, _ = build(c, flags=flags, x_scale=x_scale)
+        out.buf.fill_(float('nan'))
+        C.run_conv(make(128128))
+        got = out.read().double().cpu()
+        rms = float(ref.pow(2).mean().sqrt())
+        rel = float((got - ref).pow(2).mean().sqrt()) / rms
+        assert rel <= 3e-6 + 2.0 ** -24 / x_scale, (x_scale, flags, rel)
+
+
+def test_f16x3_output_channels_nine_decades_apart():
+    """ weights 1e-6 ... 1e3 across the output channels of one layer: every channel keeps float32-like RELATIVE accuracy because its
+    packed weights carry their own power of two (without it the small channels' lo halves would be subnormal or zero) """
+    c = [c for c in CASES if c[0] == '3x3_wide'][0]
+    c = c[:10] + (False, None, c[12])                    # no ReLU, no shortcut: the channel's own scale sets the output's
+    make, out, ref, kdepth, _, _ = build(c, channel_spread=True)
+    out.buf.fill_(float('nan'))
+    C.run_conv(make(128128))
+    got = out.read().double().cpu()
+    bias_free = ref.abs().reshape(-1, ref.shape[-1])
+    per_channel_rms = bias_free.pow(2).mean(dim=0).sqrt()
+    err = (got - ref).reshape(-1, ref.shape[-1]).pow(2).mean(dim=0).sqrt()
+    # (the 0.1-sized bias dominates the small channels' outputs; its float32 addition bounds their error at ~6e-9 absolute)
+    assert bool((err <= 2e-6 * per_channel_rms + 1e-8).all()), (err / per_channel_rms).max().item()
+
+
+def test_relu_on_a_pre_split_f16x3_map():
+    dev = torch.device('cuda')
+    x = torch.randn((2, 5, 7, 64))
+    src = C.FMap.empty(2, 5, 7, 64, torch.float32, dev, split=True, half='f16x3')
+    dst = C.FMap.empty(2, 5, 7, 64, torch.float32, dev, split=True, half='f16x3')
+    src.write(x)
+    hip.check(hip.lib().gpp_relu(hip.ptr(src.buf), hip.ptr(dst.buf), hip.GPP_F16X3, x.numel(), hip.stream_ptr()))
+    assert torch.equal(dst.read().cpu(), torch.relu(held(x)))
+
+
+def test_f16x3_arguments_are_validated():
+    c = [c for c in CASES if c[0] == '3x3_wide'][0]
+    make, _, _, _, keep, _ = build(c)
+    d = make(0)
+    d.dtype = hip.GPP_BF16X3                                   # out_scale belongs to GPP_F16X3 alone
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -1
+    d = make(0)
+    d.x3_split = 8
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -1
+    d = make(1128128)                                          # pipelined loop on a float32 input map
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -4
+    d = make(0)
+    d.out_scale = None                                         # allowed: all ones (weights packed without a scale)
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == 0

@@ -23,6 +23,9 @@ pytestmark = pytest.mark.gpu
 
 F32_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128, 128160, 192160]
 X3_TILES = F32_TILES + [128256, 192256, 256256]          # GPP_BF16X3 also has the 8-wavefront 256-column tiles (plain loop)
+# ... and not the 192 x 160 tile on float32 input maps (3 registers over the budget -> scratch: removed in round 3; the pre-split
+# form exists): GPP_ERR_UNSUPPORTED there
+X3_F32IN_TILES = [t for t in X3_TILES if t != 192160]
 
 
 def reference64(x, k, bias, stride, pad_t, pad_l, oh, ow, relu, res):
@@ -120,6 +123,9 @@ def test_conv_bf16x3_matches_float64_reference(case, tile):
     make, out, ref, kdepth, _ = _layer(case, dtype='bf16x3')
     out.buf.fill_(float('nan'))
     d = make(tile)
+    if tile == 192160:
+        assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == -4      # float32 input map: no such tile
+        return
     bn = tile % 1000 if tile else 64
     if -(-d.C_out // bn) * bn > d.weight_rows:
         pytest.skip('tile grid would read past the packed weight rows')
@@ -137,7 +143,7 @@ def test_every_bf16x3_tile_gives_identical_results(case):
     make, out, _, _, _ = _layer([c for c in CASES if c[0] == case][0], dtype='bf16x3')
     C.run_conv(make(128128))
     base = out.buf.clone()
-    for tile in X3_TILES:
+    for tile in X3_F32IN_TILES:
         out.buf.fill_(float('nan'))
         d = make(tile)
         if -(-d.C_out // (tile % 1000)) * (tile % 1000) > d.weight_rows:

@@ -175,8 +175,7 @@ def test_split_k_matches_torch_fp32(case, split):
 
 ALL_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
              1128128, 1192128, 1128256, 1192256, 256256,
-             128160, 192160, 1192160,                 # N-remainder tiles (4 x 1 wavefronts, 160 columns)
-             3064128, 3096128, 3128128, 3064256]      # loader-wavefront form (csrc/conv_ring_impl.h): 5 wavefronts, activation ring
+             128160, 192160, 1192160]                 # N-remainder tiles (4 x 1 wavefronts, 160 columns)
 
 
 def _layer(name, dtype='bf16', workspace=False):
@@ -233,31 +232,11 @@ def test_every_tile_gives_identical_results(case):
         assert torch.equal(out.buf.float().cpu(), base), tile
 
 
-@pytest.mark.parametrize('tile', [3064128, 3096128, 3128128, 3064256])
-@pytest.mark.parametrize('case', ['deepK', '3x3_wide', 'bottleneck_2c', '1x1_s2', '1x1'])
-def test_loader_wavefront_form_with_split_k_and_both_types(case, tile):
-    """ conv_ring_kernel: same bits as the plain tile with and without split-K (K-step counts 1 .. 144 around its ring depth
-    and its register sets), bf16 and f16 """
-    for dtype in ('bf16', 'f16'):
-        make, out, ref, eps = _layer(case, dtype=dtype, workspace=True)
-        if -(-make(0).C_out // (tile % 1000)) * (tile % 1000) > make(0).weight_rows:
-            continue
-        for split in (1, 2, 3):
-            nk = make(0).KH * make(0).KW * (make(0).C_in // 64)
-            if nk < split:
-                continue
-            out.buf.fill_(float('nan'))
-            C.run_conv(make(128128, split_k=split))
-            base = out.buf.float().cpu()
-            assert bool(((base - ref).abs() <= eps * ref.abs() + 1e-3).all())
-            out.buf.fill_(float('nan'))
-            C.run_conv(make(tile, split_k=split))
-            assert torch.equal(out.buf.float().cpu(), base), (dtype, split)
-
-
 def test_unknown_tile_code_is_rejected():
     make, _, _, _ = _layer('3x3')
     rc = hip.lib().gpp_conv2d_igemm(ctypes.byref(make(12345)), hip.stream_ptr())
+    assert rc == -1
+    assert hip.lib().gpp_conv2d_igemm(ctypes.byref(make(3064128)), hip.stream_ptr()) == -1      # the loader-wavefront form of round 2 is gone
     assert rc == -1
 
 
@@ -322,50 +301,6 @@ def test_bottleneck_tail_rejects_other_shapes():
     assert hip.lib().gpp_bottleneck_tail(None, None, 0, hip.stream_ptr()) == -1
     rc = hip.lib().gpp_bottleneck_tail(ctypes.byref(make(0)), ctypes.byref(make(0)), 0, hip.stream_ptr())   # 3x3 as second half
     assert rc == -4
-
-
-@pytest.mark.parametrize('tile_rows', [0, 64, 128])
-@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
-@pytest.mark.parametrize('cmid,B,H,W', [(64, 2, 25, 31), (128, 1, 26, 21), (64, 1, 7, 5), (128, 3, 9, 40)])
-def test_bottleneck_tail_next_equals_the_three_layers(cmid, B, H, W, dtype, tile_rows):
-    """ gpp_bottleneck_tail_next (3x3 + 1x1 + shortcut + the NEXT block's first 1x1 in one launch; the y tile feeds the
-    third matrix product straight from registers) must reproduce the three separate launches bit for bit. """
-    g = torch.Generator().manual_seed(7 * cmid + H)
-    tdt = C.torch_dtype(dtype)
-    dev = torch.device('cuda')
-    cout = 4 * cmid
-    a = torch.randn((B, H, W, cmid), generator=g).to(tdt)
-    k1 = (torch.randn((3, 3, cmid, cmid), generator=g) * (2.0 / (9 * cmid)) ** 0.5).to(tdt)
-    k2 = (torch.randn((1, 1, cmid, cout), generator=g) * (2.0 / cmid) ** 0.5).to(tdt)
-    k3 = (torch.randn((1, 1, cout, cmid), generator=g) * (2.0 / cout) ** 0.5).to(tdt)
-    b1d, b2d, b3d = [(torch.randn((c,), generator=g) * 0.1).to(dev) for c in (cmid, cout, cmid)]
-    sc = C.FMap(torch.randn((B, H, W, cout), generator=g).to(tdt).to(dev).contiguous(), B, H, W, cout)
-    amap = C.FMap(a.to(dev).contiguous(), B, H, W, cmid)
-    mid = C.FMap.empty(B, H, W, cmid, tdt, dev)
-    y_sep, y_fused = C.FMap.empty(B, H, W, cout, tdt, dev), C.FMap.empty(B, H, W, cout, tdt, dev)
-    z_sep, z_fused = C.FMap.empty(B, H, W, cmid, tdt, dev), C.FMap.empty(B, H, W, cmid, tdt, dev)
-    w1, w2, w3 = [C.pack_weight(k.float().numpy(), dtype, dev) for k in (k1, k2, k3)]
-    d1 = C.conv_desc([amap], [mid], w1, b1d, 3, 3, cmid, cmid, pad=(1, 1), relu=True, dtype=dtype)
-    d2 = C.conv_desc([mid], [y_sep], w2, b2d, 1, 1, cmid, cout, relu=True, residuals=[sc], dtype=dtype)
-    d3 = C.conv_desc([y_sep], [z_sep], w3, b3d, 1, 1, cout, cmid, relu=True, dtype=dtype)
-    for d in (d1, d2, d3):
-        C.run_conv(d)
-    want_y, want_z = y_sep.buf.float().cpu(), z_sep.buf.float().cpu()
-    assert want_z.abs().max() > 0
-    d2f = C.conv_desc([mid], [y_fused], w2, b2d, 1, 1, cmid, cout, relu=True, residuals=[sc], dtype=dtype)
-    d3f = C.conv_desc([y_fused], [z_fused], w3, b3d, 1, 1, cout, cmid, relu=True, dtype=dtype)
-    y_fused.buf.fill_(float('nan'))
-    z_fused.buf.fill_(float('nan'))
-    rc = hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2f), ctypes.byref(d3f), tile_rows, hip.stream_ptr())
-    if cmid == 128 and tile_rows == 128:
-        assert rc == -4                                       # C = 128 runs with 64-row tiles only
-        return
-    hip.check(rc, 'gpp_bottleneck_tail_next')
-    assert torch.equal(y_fused.buf.float().cpu(), want_y)
-    assert torch.equal(z_fused.buf.float().cpu(), want_z)
-    # the third descriptor must read the map the second one writes
-    assert hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2f), ctypes.byref(d3), tile_rows, hip.stream_ptr()) == -1
-    assert hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2f), None, tile_rows, hip.stream_ptr()) == -1
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'f16'])

@@ -46,7 +46,7 @@ def _heads(plan, batch):
             'classification_logits': plan.cls_logits.cpu().numpy().reshape(batch, -1, 8)}
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'f16', 'f32', 'bf16x3'])
+@pytest.mark.parametrize('dtype', ['bf16', 'f16', 'f32', 'bf16x3', 'f16x3'])
 def test_every_layer_at_402x1333(dtype, monkeypatch):
     check_every_layer('resnet50', dtype, '0', 2, H, WD, monkeypatch)
 
@@ -100,11 +100,33 @@ def test_f32_path_matches_the_f32_oracle_end_to_end(f32_run, oracle_lib):
 # measured (2 frames): bf16 0.905 / 0.932, f16 0.980 / 0.995; the bench line reports the same over 8 frames (bf16 0.916 / 0.895)
 LEDGER_BARS = {'bf16': {'detection_set_agreement': 0.80, 'plane_index_agreement': 0.85, 'orientation_agreement': 0.99},
                'f16': {'detection_set_agreement': 0.95, 'plane_index_agreement': 0.97, 'orientation_agreement': 0.99},
-               'bf16x3': {'detection_set_agreement': 0.98, 'plane_index_agreement': 0.98, 'orientation_agreement': 1.0}}
-RMS_BARS = {'bf16': 0.015, 'f16': 0.003, 'bf16x3': 1e-4}          # head tensors against the float32 path, relative RMS
+               'bf16x3': {'detection_set_agreement': 0.98, 'plane_index_agreement': 0.98, 'orientation_agreement': 1.0},
+               # the headline type: exactly north_star's bars (ledger.REFERENCE_BARS) -- the same detections, the same plane for every
+               # one of them, and (below) 3-D corners within 1e-3 m of the float32 path
+               'f16x3': {'detection_set_agreement': 1.0, 'plane_index_agreement': 1.0, 'orientation_agreement': 1.0}}
+RMS_BARS = {'bf16': 0.015, 'f16': 0.003, 'bf16x3': 1e-4, 'f16x3': 3e-6}          # head tensors against the float32 path, relative RMS
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'f16', 'bf16x3'])
+def test_f16x3_path_against_the_f32_CPU_oracle(f32_run, oracle_lib):
+    """ the headline type against the float32 CPU ORACLE directly (not only against the float32 HIP path): the bars of
+    test_f32_path_matches_the_f32_oracle_end_to_end -- same detections, orientations, plane indices, 3-D points within 1e-3 m """
+    r = f32_run
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='f16x3')
+    out, aidx_g, pidx_g, plan = _run(model, r['img'], r['P_inv'], r['planes'])
+    heads = _heads(plan, 2)
+    for key in ('classification_logits', 'regression', 'regression_dim'):
+        err = np.abs(heads[key] - r['oracle'][key])
+        assert err.max() < 1e-4, (key, err.max())
+    det, aidx = decode_np.detect(r['oracle']['classification_logits'], r['oracle']['regression'], r['oracle']['regression_dim'],
+                                 A.anchors_for_image((H, WD)))
+    kp, kpl, res, idx = helpers.c_oracle_poll(oracle_lib, det[0], det[1], det[4], r['P_inv'], r['planes'])
+    led = ledger.parity_ledger(list(det[:5]) + [kp, kpl, res], aidx, idx, out, aidx_g, pidx_g)
+    print('f16x3 HIP vs f32 CPU oracle:', led)
+    assert ledger.meets_reference_bars(led) and led['images_with_identical_detection_lists'] == 2, led
+    assert led['max_keypoint_dev_m_within_100m'] <= 1e-3 and led['max_keypoint_rel_dev'] <= 1e-4 and led['max_box_diff_px'] <= 1e-2, led
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16', 'bf16x3', 'f16x3'])
 def test_parity_ledger_of_the_16_bit_paths(dtype, f32_run):
     r = f32_run
     model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype=dtype)
@@ -119,6 +141,8 @@ def test_parity_ledger_of_the_16_bit_paths(dtype, f32_run):
     for key, bar in LEDGER_BARS[dtype].items():
         assert led[key] >= bar, (key, led)
     assert led['common'] > 0 and np.isfinite(led['max_corner_rel_dev'])
+    if dtype == 'f16x3':
+        assert ledger.meets_reference_bars(led), led
 
 
 def test_conv_stack_at_402x1333_matches_the_storage_oracle():

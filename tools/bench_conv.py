@@ -190,46 +190,6 @@ if __name__ == '__main__':
                 print('   mean us  phase 1 (3x3) %.2f  hand-over %.2f  phase 2 (1x1 + residual + stores) %.2f  drain %.2f  whole %.2f' %
                       (dur[:, 0].mean(), dur[:, 1].mean(), dur[:, 2].mean(), dur[:, 3].mean(), (st[:, 4] - st[:, 0]).mean()))
                 print('   starts pct 0/25/50/75/100: ' + ' '.join('%.1f' % v for v in np.percentile(st[:, 0] - t0, [0, 25, 50, 75, 100])))
-            # the same tail + the next block's first 1x1 layer in one launch, against the separate launch of that layer
-            z = C.FMap.empty(B, H, W, cmid, tdt, dev)
-            w3 = C.pack_weight((torch.randn((1, 1, cout, cmid)) * 0.05).numpy(), 'bf16', dev)
-            b3 = torch.zeros((cmid,), device=dev)
-
-            def timed(fn, n=20):
-                for _ in range(3):
-                    fn()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(n):
-                    fn()
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) * 1000.0 / n
-            for tile in (96064, 128064, 64128, 160128, 128128):
-                d3s = C.conv_desc([y], [z], w3, b3, 1, 1, cout, cmid, relu=True, dtype='bf16', tile_hint=tile)
-                print('   next 2a alone, tile %d: %.1f us' % (tile, timed(lambda: C.run_conv(d3s))))
-            for rows in (64, 128):
-                d1 = C.conv_desc([a], [mid], w1, b1, 3, 3, cmid, cmid, pad=(1, 1), relu=True, dtype='bf16', diag=16)
-                d2 = C.conv_desc([mid], [y], w2, b2, 1, 1, cmid, cout, relu=True, residuals=[sc], dtype='bf16')
-                d3 = C.conv_desc([y], [z], w3, b3, 1, 1, cout, cmid, relu=True, dtype='bf16')
-                stamps = torch.zeros((1 << 16, 8), dtype=torch.int64, device=dev)
-                d1.zero_page = stamps.data_ptr()
-                rc = hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), rows, hip.stream_ptr())
-                if rc != 0:
-                    continue
-                us = timed(lambda: hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), rows, hip.stream_ptr()))
-                stamps.zero_()
-                hip.lib().gpp_bottleneck_tail_next(ctypes.byref(d1), ctypes.byref(d2), ctypes.byref(d3), rows, hip.stream_ptr())
-                torch.cuda.synchronize()
-                st = stamps.cpu().numpy()
-                st = st[st[:, 0] != 0][:, :5].astype(np.float64) * 0.01
-                msg = ''
-                if len(st):
-                    dur = np.diff(st, axis=1)
-                    msg = '; phase 1 %.2f  hand-over %.2f  phases 2+3 %.2f  drain %.2f  whole %.2f us, %d workgroups' % (
-                        dur[:, 0].mean(), dur[:, 1].mean(), dur[:, 2].mean(), dur[:, 3].mean(), (st[:, 4] - st[:, 0]).mean(), len(st))
-                print('   tail + next 2a in one launch, rows %d: %.1f us%s' % (rows, us, msg))
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'mid':
         # the latency-bound middle of the backbone, one launch shape each (for rocprofv3 --pmc)
@@ -385,8 +345,8 @@ if __name__ == '__main__':
     bench('res5 3x3 512->512', B, [(13, 42)], 512, 512, 3)
     bench('res5 1x1 512->2048', B, [(13, 42)], 512, 2048, 1)
     bench('f16 reg tower 3x3', B, PYR, 512, 512, 3, dtype='f16')
-    if len(sys.argv) > 2 and sys.argv[2] == 'ring':
-        # loader-wavefront form (conv_ring_kernel) against the plain tiles on the latency-bound layers.  Back to back on the
+    if len(sys.argv) > 2 and sys.argv[2] == 'cold_tiles':
+        # the plain tiles on the latency-bound layers (round 2 compared the since-removed loader-wavefront form here).  Back to back on the
         # same buffers (inputs Infinity-Cache resident) AND with a 600 MB buffer rewritten between launches ("cold": inputs
         # come from HBM, closer to the network where another layer's output is what was written last)
         flush = torch.empty((600 << 20,), dtype=torch.uint8, device='cuda')
@@ -419,8 +379,6 @@ if __name__ == '__main__':
                                               ('res5 2b 3x3 512->512', [(13, 42)], 512, 512, 3, False), ('res5 2c 1x1 512->2048 +res', [(13, 42)], 512, 2048, 1, True),
                                               ('P4 3x3 512->512', [(26, 84)], 512, 512, 3, False), ('C3_reduced 1x1 512->512', [(51, 167)], 512, 512, 1, False),
                                               ('res3 2a 1x1 512->128', [(51, 167)], 512, 128, 1, False)):
-            for tile in (64128, 96128, 128128, 160128, 3064128, 3096128, 3128128, 3064256):
-                if tile == 3064256 and cout < 256:
-                    continue
+            for tile in (64128, 96128, 128128, 160128):
                 hot = bench('%s tile %d' % (name, tile), B, shp, cin, cout, k, tile=tile, residual=res, iters=20)
                 print('    cold (inputs from HBM): %.1f us   hot %.1f us' % (cold(name, shp, cin, cout, k, tile, res), hot * 1e3))
