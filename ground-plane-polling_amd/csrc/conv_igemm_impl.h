@@ -1475,8 +1475,8 @@ int launch(gpp_conv_desc& d, hipStream_t st)
     // a layer with fewer K-steps than ring slots (1x1 convs with C_in = 64) only touches the first slots:
     // declaring just those lets more workgroups share a CU, which is what the HBM-bound layers need
     const int steps = (nk + nsplit - 1) / nsplit;
-    // (the pipelined loops always stage and read both buffers: they get the whole ring and need two K-steps per split)
-    if (PIPE && nk / nsplit < 2) return GPP_ERR_UNSUPPORTED;
+    // (the pipelined loops always touch both buffers -- with a single K-step the look-ahead reads fragments of buffer 1 that nobody
+    // uses: they get the whole ring whatever the step count, never less LDS than they address)
     const int lds_used = PIPE ? lds : (steps < STAGES ? steps : STAGES) * (BM + BN) * kRowBytes;
     kernel<<<dim3((unsigned)(tiles * n_tiles), (unsigned)nsplit), dim3(64 * WM * WN), lds_used, st>>>(d);
     if (nsplit > 1) {

@@ -1,4 +1,5 @@
-""" Aggregate tools/pmc_bench.sh output for the dominant kernel -> profiles/<round>/dominant_kernel_pmc.{txt,json} """
+""" Aggregate tools/pmc_bench.sh output for the dominant kernel -> profiles/<round>/dominant_kernel_pmc_<dtype>.{txt,json}
+    python tools/pmc_aggregate.py <dir with the counter runs> <output prefix> [dtype] """
 import collections
 import csv
 import glob
@@ -6,6 +7,10 @@ import json
 import sys
 
 src, out_prefix = sys.argv[1], sys.argv[2]
+dtype = sys.argv[3] if len(sys.argv) > 3 else 'f16x3'
+CODE = {'bf16': 1, 'f16': 2, 'f32': 3, 'bf16x3': 4, 'f16x3': 5}[dtype]
+ESZ = 2 if dtype in ('bf16', 'f16') else 4
+KERNEL = 'conv_igemm_kernel<%d, 256, 256' % CODE
 # the library build the counters were collected with (bench.py prints it in roofline.library): bench.py only reports the
 # traffic figure when this matches the running library
 version = None
@@ -17,15 +22,15 @@ GRID = 722 * 512
 agg = collections.defaultdict(list)
 for f in glob.glob(src + '/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'conv_igemm_kernel<1, 256, 256' in r['Kernel_Name'] and int(r['Grid_Size']) == GRID:
+        if KERNEL in r['Kernel_Name'] and int(r['Grid_Size']) == GRID:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 mean = {k: sum(v) / len(v) for k, v in agg.items()}
 read_b = 2.0 * mean['FETCH_SIZE'] * 1024
 write_b = mean['WRITE_SIZE'] * 1024
-alg_read, alg_write = 91504 * 512 * 2 + 512 * 4608 * 2, 91504 * 512 * 2
-lines = ['library: %s' % version, 'dominant kernel = conv_igemm_kernel<bf16,256,256,2,4,2,pipe>, grid 722 x 512 threads',
+alg_read, alg_write = 91504 * 512 * ESZ + 512 * 4608 * ESZ, 91504 * 512 * ESZ
+lines = ['library: %s' % version, 'dominant kernel = conv_igemm_kernel<%s,256,256,2,4,2,pipe%s>, grid 722 x 512 threads' % (dtype, ',pre-split input' if ESZ == 4 else ''),
          '(regression tower 3x3 512->512 over the 5 pyramid levels, M = 91504 rows, B = 8)',
-         'collected with tools/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline', '']
+         'collected with tools/pmc_bench.sh: rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --dtype %s --steps 4 --warmup 2 --no-cpu-baseline' % dtype, '']
 for k in sorted(mean):
     lines.append('%-28s launches=%3d  mean per launch %.6g' % (k, len(agg[k]), mean[k]))
 lines += ['', 'Fabric-side traffic per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE count KiB at the L2 <-> fabric',
@@ -41,7 +46,7 @@ if 'SQ_VALU_MFMA_BUSY_CYCLES' in mean and 'GRBM_GUI_ACTIVE' in mean:
 if 'SQ_INSTS_VALU' in mean:
     lines.append('VALU instructions per MFMA = %.2f' % (mean['SQ_INSTS_VALU'] / mean['SQ_INSTS_MFMA']))
 open(out_prefix + '.txt', 'w').write('\n'.join(lines) + '\n')
-json.dump({'kernel': 'conv_igemm_kernel<bf16,256,256,2,4,2,pipe>', 'grid': GRID, 'library_version': version, 'traffic_bytes_per_launch': read_b + write_b,
+json.dump({'kernel': 'conv_igemm_kernel<%s,256,256,2,4,2,pipe>' % dtype, 'dtype': dtype, 'grid': GRID, 'library_version': version, 'traffic_bytes_per_launch': read_b + write_b,
            'read_bytes': read_b, 'write_bytes': write_b, 'algorithmic_bytes': alg_read + alg_write,
            'counters': mean}, open(out_prefix + '.json', 'w'), indent=1)
 print('\n'.join(lines))

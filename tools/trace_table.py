@@ -24,14 +24,15 @@ def conv_names(backbone, fused_stages=(0, 1)):
 
 
 def short(k):
-    m = re.search(r'bottleneck_tail_kernel<(\d+), (\d+), (\d+)(?:, (\w+))?>', k)
+    m = re.search(r'bottleneck_tail_kernel<(\d+), (\d+), (\d+)>', k)
     if m:
-        return 'fused tail %sx%s%s' % (m.group(2), m.group(3), ' +next2a' if m.group(4) in ('true', '1') else '')
+        return 'fused tail %sx%s' % (m.group(2), m.group(3))
     if 'conv_igemm_dual_kernel' in k:
         return 'igemm 256x256 + 512x128 (dual grid)'
-    m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>', k)
+    m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?>', k)
     if m:
-        return 'igemm %sx%s w%sx%s s%s%s' % (m.group(2), m.group(3), m.group(4), m.group(5), m.group(6), ' pipe' if m.group(7) in ('true', '1') else '')
+        return 'igemm %sx%s w%sx%s%s%s' % (m.group(2), m.group(3), m.group(4), m.group(5), ' pipe' if m.group(7) in ('true', '1') else '',
+                                         ' xin' if m.group(8) in ('true', '1') else '')
     for key in ('stem_pool_mfma', 'stem_mfma', 'stem_kernel', 'maxpool', 'relu', 'splitk_reduce', 'clear_counters', 'candidates', 'nms', 'emit_kernel', 'canonical_planes', 'poll'):
         if key in k:
             return key
