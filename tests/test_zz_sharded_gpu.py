@@ -90,3 +90,24 @@ def test_two_process_shards_equal_the_single_process_batch(dtype, tmp_path, orac
     # and each image alone (another plan, another batch size) gives the same bytes again
     alone = single_run(slice(1, 2))
     assert alone.tobytes() == single[1:2].tobytes()
+
+
+@pytest.mark.gpu
+def test_rccl_branch_of_the_gather(tmp_path):
+    """ The driver's multi-GPU run gathers over RCCL; the two-process test above uses gloo (one GPU).  Here a child process forms
+    a one-rank RCCL group and runs the same ShardedModel / gather_detections code (all_gather_into_tensor on the device, synchronous
+    and asynchronous): both must return the bytes of a plain single-process predict_on_batch. """
+    from keras_retinanet_3D import models
+    import sharded_worker
+    batch, h, w = 2, 402, 1333
+    out_path = str(tmp_path / 'rccl.npy')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'rccl_worker.py'), str(_free_port()), str(batch), str(h), str(w), 'f16x3', out_path],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    got = np.load(out_path)
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='f16x3')
+    outs = model.predict_on_batch(list(sharded_worker.global_inputs(batch, h, w)))
+    single = np.concatenate([np.asarray(o, np.float32).reshape(batch, 100, -1) for o in outs], axis=2)
+    assert got.shape == (2, batch, 100, 35)
+    assert got[0].tobytes() == single.tobytes() and got[1].tobytes() == single.tobytes()
