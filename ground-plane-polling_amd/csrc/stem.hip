@@ -224,6 +224,140 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
     }
 }
 
+// ---- MFMA stem for the float32-storage "x3" types (GPP_F16X3 / GPP_BF16X3 models) ------------------------------------
+// The same GEMM view as stem_mfma_kernel, at (almost) float32 precision: input pixels and weights are each split into two IEEE
+// halves (hi = f16(v), lo = f16(v - hi): 22 significant bits; |x| <= 152 and the weights carry a per-channel power of two, so both
+// halves are normal halfs) and every product is three matrix products, hi*whi + hi*wlo + lo*whi, accumulated in float32; the
+// output is float32.  Replaces the float32 fmaf stem of rounds 1-2 for these types: that kernel ran at a fifth of the vector peak
+// and lost another third of its speed when the packed-FP32 instructions went (372 us at B = 8; this one: see DESIGN 4.9).
+// ROWS wavefronts per workgroup, each owning one output row of 64 pixels x 64 channels of a ROWS x 64 tile; persistent workgroups.
+// Packed weights: [whi 64 x 232 halfs][wlo 64 x 232 halfs][64 float32 out_scale] (gpp_stem_pack_weights_f16x3).
+template <int ROWS>
+__global__ __launch_bounds__(64 * ROWS) void stem_mfma_x3_kernel(const float* __restrict__ in, const _Float16* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int B, int H, int W, int Ho, int Wo)
+{
+    constexpr int NT = 64 * ROWS, PROWS = ROWS * 2 + 5;
+    constexpr int W_HALFS = 64 * MW_PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    _Float16* s_wh = (_Float16*)xsm;
+    _Float16* s_wl = s_wh + W_HALFS;
+    _Float16* s_ph = s_wl + W_HALFS;
+    _Float16* s_pl = s_ph + PROWS * MP_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 2 * W_HALFS / 8; e += NT) ((uint4*)s_wh)[e] = ((const uint4*)w)[e];
+    const float* scale = (const float*)(w + 2 * W_HALFS);
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + ROWS - 1) / ROWS;
+    const int tiles = tiles_x * tiles_y * B;
+    const int frow = lane & 15, fq = lane >> 4;
+    float bias_v[2][8], scale_v[2][8];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bias_v[jj][e] = bias[jj * 32 + fq * 8 + e]; scale_v[jj][e] = scale[jj * 32 + fq * 8 + e]; }
+
+    constexpr int PATCH_PAIRS = PROWS * (MP_PITCH / 2);
+    constexpr int PATCH_IT = (PATCH_PAIRS + NT - 1) / NT;
+    float patch[PATCH_IT][2];
+    auto load_patch = [&](int t) {
+        const int b = t / (tiles_x * tiles_y), r = t - b * (tiles_x * tiles_y);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int ix0 = tx * TW * 2 - 3, iy0 = ty * ROWS * 2 - 3;
+        const float* img = in + (size_t)b * H * W * 3;
+#pragma unroll
+        for (int it = 0; it < PATCH_IT; ++it) {
+            const int e = tid + it * NT;
+            const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
+            const int iy = iy0 + pr;
+            const int x0 = ix0 * 3 + c2;
+            float v0 = 0.0f, v1 = 0.0f;
+            if (e < PATCH_PAIRS && (unsigned)iy < (unsigned)H) {
+                const float* rowp = img + (size_t)iy * W * 3;
+                if (x0 >= 0 && x0 < W * 3) v0 = rowp[x0];
+                if (x0 + 1 >= 0 && x0 + 1 < W * 3) v1 = rowp[x0 + 1];
+            }
+            patch[it][0] = v0;
+            patch[it][1] = v1;
+        }
+    };
+    if ((int)blockIdx.x < tiles) load_patch(blockIdx.x);
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int b = t / (tiles_x * tiles_y), r = t - b * (tiles_x * tiles_y);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int ox0 = tx * TW, oy0 = ty * ROWS;
+        __syncthreads();                                     // previous tile's readers are done with the patch
+#pragma unroll
+        for (int it = 0; it < PATCH_IT; ++it) {
+            const int e = tid + it * NT;
+            const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
+            if (e < PATCH_PAIRS) {
+                const _Float16 h0 = (_Float16)patch[it][0], h1 = (_Float16)patch[it][1];
+                *(f16x2*)(s_ph + pr * MP_PITCH + c2) = (f16x2){h0, h1};
+                *(f16x2*)(s_pl + pr * MP_PITCH + c2) = (f16x2){(_Float16)(patch[it][0] - (float)h0), (_Float16)(patch[it][1] - (float)h1)};
+            }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < tiles) load_patch(t + gridDim.x);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            f16x8 wh[4], wl[4], xh[4], xl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wh[j] = *(const f16x8*)(s_wh + (j * 16 + frow) * MW_PITCH + kh * 32 + fq * 8);
+                wl[j] = *(const f16x8*)(s_wl + (j * 16 + frow) * MW_PITCH + kh * 32 + fq * 8);
+            }
+            const int poff = (wave * 2 + kh) * MP_PITCH + fq * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x2* sh = (const f16x2*)(s_ph + poff + (i * 16 + frow) * 6);
+                const f16x2* sl = (const f16x2*)(s_pl + poff + (i * 16 + frow) * 6);
+                const f16x2 a0 = sh[0], a1 = sh[1], a2 = sh[2], a3 = sh[3];
+                const f16x2 c0 = sl[0], c1 = sl[1], c2 = sl[2], c3 = sl[3];
+                xh[i] = (f16x8){a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+                xl[i] = (f16x8){c0[0], c0[1], c1[0], c1[1], c2[0], c2[1], c3[0], c3[1]};
+            }
+            // three products per accumulator; consecutive matrix instructions go to different accumulators
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+        }
+        const int oy = oy0 + wave;
+        if (oy < Ho) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ox = ox0 + i * 16 + frow;
+                if (ox >= Wo) continue;
+                float* dst = out + (((size_t)b * Ho + oy) * Wo + ox) * 64;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    f32x4 v0, v1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = fmaxf(acc[i][2 * jj][e] * scale_v[jj][e] + bias_v[jj][e], 0.0f);
+                        v1[e] = fmaxf(acc[i][2 * jj + 1][e] * scale_v[jj][4 + e] + bias_v[jj][4 + e], 0.0f);
+                    }
+                    *(f32x4*)(dst + jj * 32 + fq * 8) = v0;
+                    *(f32x4*)(dst + jj * 32 + fq * 8 + 4) = v1;
+                }
+            }
+        }
+    }
+}
+
 // ---- MFMA stem fused with pool1 -------------------------------------------------------------------
 // conv1 + bn_conv1 + ReLU + the 3x3 stride-2 'same' max-pool in one launch: the (B, Ho, Wo, 64) conv map -- 137 MB at
 // B = 8, 402 x 1333, written by the stem and read back by the pool -- never exists.  A persistent workgroup of 8
@@ -510,6 +644,59 @@ extern "C" int gpp_stem_pack_weights_f16(const float* host_weight_147x64, void* 
         }
     }
     return GPP_OK;
+}
+
+extern "C" int gpp_stem_pack_weights_f16x3(const float* host_weight_147x64, void* host_packed, size_t packed_bytes)
+{
+    // host-side helper: [147][64] float32 -> [whi 64 x 232 halfs][wlo 64 x 232 halfs][64 float32 out_scale]; channel n's weights are
+    // multiplied by 2^k(n) (largest weight of the channel in [2^13, 2^14)) before they are split into two halves, out_scale[n] =
+    // 2^-k(n); rows interleaved and k ordered as gpp_stem_pack_weights_f16
+    const size_t need = (size_t)2 * 64 * MW_PITCH * 2 + 64 * sizeof(float);
+    if (!host_weight_147x64 || !host_packed || packed_bytes < need) return GPP_ERR_BAD_ARG;
+    _Float16* hi = (_Float16*)host_packed;
+    _Float16* lo = hi + 64 * MW_PITCH;
+    float* out_scale = (float*)(lo + 64 * MW_PITCH);
+    for (int pos = 0; pos < 64; ++pos) {
+        const int g = pos / 32, within = pos % 32, h = within / 16, q = (within % 16) / 4, r = within % 4;
+        const int n = g * 32 + 8 * q + 4 * h + r;
+        float amax = 0.0f;
+        for (int k = 0; k < 147; ++k) amax = fmaxf(amax, fabsf(host_weight_147x64[k * 64 + n]));
+        int e = 0;
+        if (amax > 0.0f) { (void)frexpf(amax, &e); e = 14 - e; }          // amax = m * 2^(14 - e_new), m in [0.5, 1) -> amax * 2^e in [2^13, 2^14)
+        const float sc = ldexpf(1.0f, e);
+        out_scale[n] = ldexpf(1.0f, -e);
+        for (int k = 0; k < MW_PITCH; ++k) {
+            const int kh = k / 32, kc = k % 32;
+            float v = 0.0f;
+            if (k < 224 && kc < 21) v = host_weight_147x64[(kh * 21 + kc) * 64 + n] * sc;
+            const _Float16 vh = (_Float16)v;
+            hi[pos * MW_PITCH + k] = vh;
+            lo[pos * MW_PITCH + k] = (_Float16)(v - (float)vh);
+        }
+    }
+    return GPP_OK;
+}
+
+extern "C" int gpp_stem_conv7x7_bn_relu_x3(const float* in, const void* packed_weight_x3, const float* bias, float* out,
+                                           int B, int H, int W, void* stream)
+{
+    if (!in || !packed_weight_x3 || !bias || !out || B <= 0 || H <= 0 || W <= 0) return GPP_ERR_BAD_ARG;
+    if (((uintptr_t)out | (uintptr_t)packed_weight_x3) & 15) return GPP_ERR_ALIGN;
+    constexpr int ROWS = 8;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const int tiles = ((Wo + TW - 1) / TW) * ((Ho + ROWS - 1) / ROWS) * B;
+    const int lds = 2 * 64 * MW_PITCH * 2 + 2 * (ROWS * 2 + 5) * MP_PITCH * 2;
+    static std::atomic<unsigned long long> configured{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GPP_ERR_UNSUPPORTED;
+    if (!(configured.load(std::memory_order_acquire) >> dev & 1ull)) {
+        hipError_t e = hipFuncSetAttribute((const void*)stem_mfma_x3_kernel<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        configured.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);                           // persistent workgroups, one per CU
+    stem_mfma_x3_kernel<ROWS><<<grid, 64 * ROWS, lds, (hipStream_t)stream>>>(in, (const _Float16*)packed_weight_x3, bias, out, B, H, W, Ho, Wo);
+    return result();
 }
 
 extern "C" int gpp_stem_conv7x7_bn_relu_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,

@@ -87,6 +87,10 @@ def _declare(lib):
     lib.gpp_stem_conv7x7_bn_relu_mfma.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.gpp_stem_pack_weights_f16.restype = c_int
     lib.gpp_stem_pack_weights_f16.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.gpp_stem_pack_weights_f16x3.restype = c_int
+    lib.gpp_stem_pack_weights_f16x3.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.gpp_stem_conv7x7_bn_relu_x3.restype = c_int
+    lib.gpp_stem_conv7x7_bn_relu_x3.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.gpp_stem_pool_fused_mfma.restype = c_int
     lib.gpp_stem_pool_fused_mfma.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.gpp_maxpool3x3s2_same.restype = c_int
@@ -184,6 +188,16 @@ def ptr(t):
         return None
     assert t.is_contiguous(), 'gpp kernels need dense tensors'
     return ctypes.c_void_p(t.data_ptr())
+
+
+def pack_stem_weights_x3(kernel_147x64, device):
+    """ [147][64] float32 folded stem kernel -> device blob of the x3 MFMA stem: [whi 64 x 232 f16][wlo 64 x 232 f16][64 float32 out_scale] """
+    import numpy as np
+    import torch
+    src = np.ascontiguousarray(kernel_147x64, dtype=np.float32)
+    dst = np.zeros((2 * 64 * 232 * 2 + 64 * 4,), dtype=np.uint8)
+    check(lib().gpp_stem_pack_weights_f16x3(src.ctypes.data_as(c_void_p), dst.ctypes.data_as(c_void_p), dst.nbytes), 'gpp_stem_pack_weights_f16x3')
+    return torch.as_tensor(dst).to(device).contiguous()
 
 
 def pack_stem_weights(kernel_147x64, device):

@@ -158,7 +158,11 @@ class RetinaNet3D(object):
             if k.shape != (kh, kw, cin, cout):
                 raise ValueError('weight {} has shape {}, expected {}'.format(conv, k.shape, (kh, kw, cin, cout)))
             if conv == 'conv1':
-                if self.esz == 4:            # float32 stem on the vector ALUs: the folded kernel as it is, [147][64]
+                if self.dtype in C.X3_TYPES and os.environ.get('GPP_X3_STEM', 'mfma') != 'valu':
+                    # the x3 types: conv1 on the matrix pipe, input and weights split into two IEEE halves (csrc/stem.hip)
+                    self.stem_w = hip.pack_stem_weights_x3(k.reshape(147, 64), dev)
+                    self.stem_x3 = True
+                elif self.esz == 4:          # float32 stem on the vector ALUs: the folded kernel as it is, [147][64]
                     self.stem_w = torch.as_tensor(np.ascontiguousarray(k.reshape(147, 64), dtype=np.float32)).to(dev).contiguous()
                 else:
                     self.stem_w = hip.pack_stem_weights(k.reshape(147, 64), dev)
@@ -254,7 +258,7 @@ class RetinaNet3D(object):
         else:
             stem = fmap(H1, W1, 64)
             d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
-                         C.gpp_storage_dtype(self.dtype), B, H, Wd)
+                         hip.GPP_F16X3 if getattr(self, 'stem_x3', False) else C.gpp_storage_dtype(self.dtype), B, H, Wd)
             plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
             plan.stem_out = stem
             plan.add(OP_MAXPOOL, PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_storage_dtype(self.dtype), B, H1, W1, 64, 0), 'pool1')

@@ -233,6 +233,13 @@ int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B, int H, in
 /* conv1 + bn_conv1 + ReLU + pool1 in ONE launch (GPP_BF16 / GPP_F16): out is the POOLED map (B, Hp, Wp, 64), Hp = (Ho + 1)/2;
  * the (B, Ho, Wo, 64) conv map is never written (137 MB at B = 8, 402 x 1333).  Bit-identical to
  * gpp_stem_conv7x7_bn_relu_mfma followed by gpp_maxpool3x3s2_same (the max is taken over the rounded conv values). */
+/* The stem of the float32-storage "x3" types (GPP_F16X3 / GPP_BF16X3 models): conv1 + bn_conv1 + ReLU on the matrix pipe at
+ * (almost) float32 precision -- input pixels and weights split into two IEEE halves each, three matrix products per float32 product,
+ * float32 output (B, Ho, Wo, 64).  packed_weight_x3 = what the HOST-side helper gpp_stem_pack_weights_f16x3 writes from the folded
+ * [147][64] kernel: 2 * 64 * 232 halfs + 64 float32 (59 648 bytes). */
+int gpp_stem_pack_weights_f16x3(const float* host_weight_147x64, void* host_packed, size_t packed_bytes);
+int gpp_stem_conv7x7_bn_relu_x3(const float* in, const void* packed_weight_x3, const float* bias, float* out,
+                                int B, int H, int W, void* stream);
 int gpp_stem_pool_fused_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
                              int dtype, int B, int H, int W, void* stream);
 /* dtype GPP_BF16X3 = a pre-split map (gpp_conv_desc.x3_split): ReLU on the [hi | lo] pairs (count in float32-sized elements, a
@@ -349,7 +356,7 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 #define GPP_OP_SYNC 0x20000
 
 typedef struct gpp_stem_desc { const float* in; const void* weight; const float* bias; void* out;
-                               int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem); GPP_F32: float32 [147][64] */
+                               int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem); GPP_F32: float32 [147][64]; GPP_F16X3: gpp_stem_pack_weights_f16x3 */
 typedef struct gpp_pool_desc { const void* in; void* out; int32_t dtype, B, H, W, C, reserved; } gpp_pool_desc;
 typedef struct gpp_relu_desc { const void* in; void* out; int64_t in_bstride, out_bstride, count;
                                int32_t dtype, B; } gpp_relu_desc;

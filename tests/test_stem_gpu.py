@@ -39,6 +39,34 @@ def test_stem_matches_torch(B, H, W, dtype, tdt, eps):
     assert err2.mean().item() < 0.1 * (2.0 ** -10 * bound).mean().item() + eps * ref.abs().mean().item()
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 37, 53), (1, 64, 131), (3, 17, 300), (2, 402, 1333)])
+def test_x3_stem_matches_float64(B, H, W):
+    """ the matrix-pipe stem of the float32-storage x3 types (gpp_stem_conv7x7_bn_relu_x3): pixels and weights split into two IEEE
+    halves each, three products per float32 product, per-channel power-of-two weight scale.  Against float64 on the float32 operands:
+    |err| <= 1e-5 |ref| + 2e-6 rms(ref) sqrt(147) (the float32 conv bar of tests/test_conv_f32_gpu.py) and rms(err) <= 5e-7 rms(ref);
+    channels whose weights are four decades apart keep that relative accuracy; ragged map edges and tiles (8-row workgroup tiles) """
+    g = torch.Generator().manual_seed(H * W + B)
+    x = torch.rand((B, H, W, 3), generator=g) * 255.0 - 120.0
+    k = torch.randn((7, 7, 3, 64), generator=g) * 0.05 * torch.pow(10.0, torch.linspace(-2.0, 2.0, 64))[None, None, None, :]
+    bias = torch.randn((64,), generator=g) * 0.1
+    ref = torch.relu(F.conv2d(F.pad(x.double().permute(0, 3, 1, 2), (3, 3, 3, 3)), k.double().permute(3, 2, 0, 1), bias.double(), stride=2)).permute(0, 2, 3, 1)
+    pre = F.conv2d(F.pad(x.double().permute(0, 3, 1, 2), (3, 3, 3, 3)), k.double().permute(3, 2, 0, 1), None, stride=2).permute(0, 2, 3, 1)
+    Ho, Wo = ref.shape[1:3]
+    dev = torch.device('cuda')
+    out = torch.full((B, Ho, Wo, 64), float('nan'), dtype=torch.float32, device=dev)
+    xd, bd = x.to(dev).contiguous(), bias.to(dev)
+    packed = hip.pack_stem_weights_x3(k.reshape(147, 64).numpy(), dev)
+    hip.check(hip.lib().gpp_stem_conv7x7_bn_relu_x3(hip.ptr(xd), hip.ptr(packed), hip.ptr(bd), hip.ptr(out), B, H, W, hip.stream_ptr()))
+    got = out.double().cpu()
+    assert torch.isfinite(got).all()
+    rms_c = pre.reshape(-1, 64).pow(2).mean(dim=0).sqrt()                    # per channel: the channels differ by four decades
+    err = (got - ref).abs().reshape(-1, 64)
+    tol = 1e-5 * ref.abs().reshape(-1, 64) + 2e-6 * 147 ** 0.5 * rms_c[None, :]
+    assert bool((err <= tol).all()), (err / rms_c[None, :]).max().item()
+    assert bool((err.pow(2).mean(dim=0).sqrt() <= 5e-7 * rms_c + 1e-8).all()), (err.pow(2).mean(dim=0).sqrt() / rms_c).max().item()
+    assert hip.lib().gpp_stem_conv7x7_bn_relu_x3(None, hip.ptr(packed), hip.ptr(bd), hip.ptr(out), B, H, W, hip.stream_ptr()) == -1
+
+
 @pytest.mark.parametrize('B,H,W,C', [(2, 19, 27, 64), (1, 20, 28, 64), (1, 201, 667, 64)])
 def test_maxpool_matches_torch(B, H, W, C):
     g = torch.Generator().manual_seed(H)
