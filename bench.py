@@ -64,7 +64,7 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-f32-leg', action='store_true', help='skip the float32 leg + parity ledger of a 16-bit run')
     p.add_argument('--no-host-fed', action='store_true', help='skip the host-fed (PCIe-inclusive) legs')
-    p.add_argument('--cpu-images', type=int, default=2)
+    p.add_argument('--cpu-images', type=int, default=4, help='frames of the bounded CPU-baseline sample (about 3.5 s each on 128 host threads)')
     return p.parse_args()
 
 
@@ -486,7 +486,8 @@ def main():
                 print(json.dumps(rec))
                 raise SystemExit('decode / polling of the GPU head tensors differ from the oracle replay')
         print(json.dumps(rec))
-        if bars_met is False and args.dtype in ('f16x3',):
+        headline = args.dtype == 'f16x3' and args.backbone == 'resnet50' and args.planes == '1k' and B == 8
+        if bars_met is False and headline:           # (other configurations report parity_bars_met and carry on)
             raise SystemExit('the headline type {} misses a reference-precision bar: {}'.format(args.dtype, parity))
     for e in events:
         lib.gpp_event_destroy(e)

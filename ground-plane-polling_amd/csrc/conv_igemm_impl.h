@@ -616,7 +616,8 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     };
     // (... and only where it costs at most 16 registers beside at most 96 accumulator registers: the 160-column tiles (40 registers
     // of bias) and the plain 256 x 256 tile spilled with it)
-    constexpr bool BIASPRE = !PIPE && NF <= 4 && MF * NF <= 24 && DT != GPP_F16X3;      // (GPP_F16X3 fetches bias AND scale: in the epilogue)
+    // (GPP_F16X3 fetches bias AND scale, 32 registers: under the loop only on pre-split input maps -- no split temporaries -- and small tiles)
+    constexpr bool BIASPRE = !PIPE && NF <= 4 && MF * NF <= (DT == GPP_F16X3 ? (XIN ? 16 : 0) : 24);
     if constexpr (BIASPRE) load_bias();
 
     GPP_STAMP(1);
