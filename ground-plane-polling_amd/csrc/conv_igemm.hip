@@ -167,7 +167,7 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 // One list for the autotuner below and for gpp_conv2d_tile_candidates (tests draw tiles at random from it).
 static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                              1128128, 1192128, 1128256, 1192256, 256256, 1256256,
-                             128160, 192160, 1192160, 2256256,
+                             128160, 192160, 1192160, 1128160, 2256256,
                              128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
 // (the loader-wavefront form of round 2, tile codes 3064128 ..., measured 1.5 - 2x slower on every layer it was built for
 // (profiles/r2/ring_kernel.txt), is no longer part of the library)
