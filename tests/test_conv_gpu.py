@@ -96,7 +96,7 @@ def test_conv_matches_torch_fp32(case, dtype, tile):
     assert abs(C.conv_flops(d) - 2.0 * B * oh * ow * K * K * Cin * Cout) < 1.0
 
 
-@pytest.mark.parametrize('tile', [128, 256, 3064128, 3128128])
+@pytest.mark.parametrize('tile', [128, 256, 1128160, 1192128])
 def test_grouped_pyramid_launch_and_channel_slices(tile):
     """ five feature maps of different sizes in one launch, inputs read as a channel slice of a
     wider tensor, outputs written at level offsets of one (B, sum(HW), C) pyramid tensor """
