@@ -32,6 +32,10 @@ def parse_args(args):
     parser.add_argument('--subset', help='Subset to evaluate.', default='val')
     parser.add_argument('--backbone', help='The backbone of the model to load.', default='resnet50')
     parser.add_argument('--batch-size', help='Images per predict_on_batch call.', type=int, default=1)
+    parser.add_argument('--dtype', default='f16x3', choices=['f16x3', 'f32', 'bf16x3', 'f16', 'bf16'],
+                        help='Arithmetic of the conv stack (not in the reference CLI).  Default f16x3: the fastest type whose detections, plane '
+                             'indices and 3-D corners stay within 1e-3 of the float32 (reference floatx) path; f32 = floatx itself; '
+                             'bf16x3 / f16 / bf16 are faster and leave that tolerance.')
     parser.add_argument('--iou-threshold', type=float, default=0.5)
     parser.add_argument('--score-threshold', type=float, default=0.05)
     parser.add_argument('--max-detections', type=int, default=100)
@@ -41,7 +45,7 @@ def parse_args(args):
 
 def main(args=None):
     args = parse_args(sys.argv[1:] if args is None else args)
-    model = models.load_model(args.model_path, backbone_name=args.backbone)
+    model = models.load_model(args.model_path, backbone_name=args.backbone, dtype=args.dtype)
     generator = KittiGenerator(args.kitti_dir, subset=args.subset, plane_params_path=args.plane_params_path)
     results = evaluate(generator, model, iou_threshold=args.iou_threshold, score_threshold=args.score_threshold,
                        max_detections=args.max_detections, batch_size=args.batch_size)

@@ -49,6 +49,10 @@ def parse_args(args):
     parser.add_argument('--save-images', help='Include to save result images.', action='store_true')
     parser.add_argument('--backbone', help='The backbone of the model to load.', default='resnet50')
     parser.add_argument('--batch-size', help='Images per predict_on_batch call.', type=int, default=1)
+    parser.add_argument('--dtype', default='f16x3', choices=['f16x3', 'f32', 'bf16x3', 'f16', 'bf16'],
+                        help='Arithmetic of the conv stack (not in the reference CLI).  Default f16x3: the fastest type whose detections, plane '
+                             'indices and 3-D corners stay within 1e-3 of the float32 (reference floatx) path; f32 = floatx itself; '
+                             'bf16x3 / f16 / bf16 are faster and leave that tolerance.')
     return parser.parse_args(args)
 
 
@@ -98,7 +102,7 @@ def main(args=None):
         args = sys.argv[1:]
     args = parse_args(args)
 
-    model = models.load_model(args.model_path, backbone_name=args.backbone)
+    model = models.load_model(args.model_path, backbone_name=args.backbone, dtype=args.dtype)
     plane_params = scipy.io.loadmat(args.plane_params_path)['road_planes_database']
     output_dir = make_output_tree(args)
 
