@@ -95,7 +95,9 @@ int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int t
     if (rc != GPP_OK) return rc;
     const gpp_conv_group &G1 = d1.groups[0], &G2 = d2.groups[0];
     // the pair this kernel fuses: 3x3 / stride 1 / pad 1 / C -> C (C = 64 or 128) feeding 1x1 / stride 1 / C -> multiple of 128
-    if (f32_storage(d1.dtype)) return GPP_ERR_UNSUPPORTED;         // 16-bit storage types only
+    if (d1.dtype == GPP_F32) return GPP_ERR_UNSUPPORTED;           // 16-bit storage types, and the x3 types on pre-split maps
+    if (is_x3(d1.dtype) && (!(d1.x3_split & GPP_X3_IN) || (d2.x3_split & (GPP_X3_OUT | GPP_X3_RES)) != (GPP_X3_OUT | GPP_X3_RES) || !d2.residual))
+        return GPP_ERR_UNSUPPORTED;
     if (d1.dtype != d2.dtype || d1.n_groups != 1 || d2.n_groups != 1 || d1.batch != d2.batch) return GPP_ERR_UNSUPPORTED;
     if (d1.KH != 3 || d1.KW != 3 || d1.stride != 1 || d1.pad_top != 1 || d1.pad_left != 1 || d1.residual || d1.out_f32) return GPP_ERR_UNSUPPORTED;
     if (d1.C_in != d1.C_out || (d1.C_in != 64 && d1.C_in != 128) || d1.weight_rows < d1.C_out) return GPP_ERR_UNSUPPORTED;
@@ -104,7 +106,12 @@ int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int t
     if (G1.H_in != G1.H_out || G1.W_in != G1.W_out || G2.H_out != G1.H_out || G2.W_out != G1.W_out || G2.H_in != G1.H_out || G2.W_in != G1.W_out)
         return GPP_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    return d1.dtype == GPP_BF16 ? gpp_tail_dispatch_bf16(d1, d2, tile_rows, st) : gpp_tail_dispatch_f16(d1, d2, tile_rows, st);
+    switch (d1.dtype) {
+        case GPP_BF16: return gpp_tail_dispatch_bf16(d1, d2, tile_rows, st);
+        case GPP_F16: return gpp_tail_dispatch_f16(d1, d2, tile_rows, st);
+        case GPP_BF16X3: return gpp_tail_dispatch_bf16x3(d1, d2, tile_rows, st);
+        default: return gpp_tail_dispatch_f16x3(d1, d2, tile_rows, st);
+    }
 }
 
 }  // namespace

@@ -4,3 +4,8 @@
 #include "conv_igemm_types.h"
 
 int gpp_conv_dispatch_f16x3(gpp_conv_desc& d, hipStream_t st) { return dispatch<GPP_F16X3>(d, st); }
+
+int gpp_tail_dispatch_f16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st)
+{
+    return dispatch_tail_x3<GPP_F16X3>(d1, d2, tile_rows, st);
+}

@@ -1426,6 +1426,301 @@ int prepare(gpp_conv_desc& d)
     return tiles;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The fused bottleneck tail for the float32-storage x3 types (GPP_BF16X3 / GPP_F16X3) on PRE-SPLIT maps: the same two phases as
+// bottleneck_tail_kernel with every matrix product in its three-product form (hi*wlo, hi*whi, lo*whi per 32-channel K-step, the order
+// of every x3 tile) and the intermediate tile written to LDS as the [32 hi | 32 lo] rows the unfused 3x3 layer would have stored
+// (acc * out_scale + bias, ReLU, clamp, split): bit-identical to the two separate launches.  Input map, shortcut map and output map
+// are pre-split (x3_split: d1 GPP_X3_IN; d2 GPP_X3_OUT | GPP_X3_RES); the 69 MB (res2, B = 8) intermediate map is never written.
+// LDS: max(two phase-1 stages, intermediate tile + one 128-row tile of W2) -- 64 KB for C = 64 at 128 rows: two workgroups per CU.
+template <int DT, int BM, int CMID>
+__global__ __launch_bounds__(256, 2) void bottleneck_tail_x3_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2)
+{
+    static_assert(kX3<DT>, "x3 types");
+    using xh8 = typename X3Half<DT>::vec;
+    constexpr bool OSCALE = (DT == GPP_F16X3);
+    constexpr int WM = 2, WN = 2, NW = 4, P2M = 2, P2N = 2;
+    constexpr int MF = BM / WM / 16, NF1 = CMID / WN / 16;
+    constexpr int MF2 = BM / P2M / 16, NF2 = 128 / P2N / 16, COLS2 = 128 / P2N;
+    constexpr int KC = CMID / 32;                                          // 32-channel K-steps of the intermediate
+    constexpr int A_BYTES = BM * kRowBytes, B_BYTES = CMID * kRowBytes, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_IT = BM / 8 / NW, B_IT = CMID / 8 / NW;
+    constexpr int T_BYTES = KC * A_BYTES;
+    constexpr int W2_IT = 128 / 8 / NW;
+    static_assert(BM % 32 == 0 && (CMID == 64 || CMID == 128) && NF1 % 2 == 0, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int mt = xcd_remap(blockIdx.x, gridDim.x);
+    const gpp_conv_group& G1 = d1.groups[0];
+    const gpp_conv_group& G2 = d2.groups[0];
+    const int H = G1.H_out, W = G1.W_out, HW = H * W;
+    const int Mg = d1.batch * HW;
+    const int m0 = mt * BM;
+
+    // ---- phase 1: 3x3 conv over the pre-split input map (float32-sized elements: 4 bytes)
+    const int srow = lane >> 3;
+    const int gchunk = (lane & 7) ^ srow;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d1.in, 0, d1.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d1.weight, 0, d1.weight_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d2.weight, 0, d2.weight_bytes, 0x00020000);
+    int a_base[A_IT], a_mask[A_IT], a_voff[A_IT];
+    const int pitch4 = d1.in_pitch * 4;
+    {
+        PixWalk pw;
+        pw.init(m0 + wave * A_IT * 8 + srow, HW, W);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + (wave * A_IT + i) * 8 + srow;
+            a_mask[i] = 0;
+            a_base[i] = 0;
+            if (m < Mg) {
+                const int iy0 = pw.oy - 1, ix0 = pw.ox - 1;
+                int mask = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) mask |= (((unsigned)(iy0 + k) < (unsigned)H) << k) | (((unsigned)(ix0 + k) < (unsigned)W) << (8 + k));
+                a_mask[i] = mask;
+                a_base[i] = (int)((G1.in_off + (int64_t)pw.b * G1.in_bstride) * 4) + gchunk * 16 + (iy0 * W + ix0) * pitch4;
+            }
+            if (i + 1 < A_IT) pw.advance(8, H, W);
+        }
+    }
+    constexpr int Ktot1 = 9 * CMID;
+    int w_voff[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) w_voff[i] = ((wave * B_IT + i) * 8 + srow) * Ktot1 * 4 + gchunk * 16;
+    auto set_tap = [&](int kh, int kw) {
+        const int delta = (kh * W + kw) * pitch4;
+        const int need = (1 << kh) | (1 << (8 + kw));
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) a_voff[i] = ((a_mask[i] & need) == need) ? a_base[i] + delta : kOutOfRange;
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    const int wm2 = wave / P2N, wn2 = wave % P2N;
+    int a_rd[2], b1_rd[2], a_rd2[2], b2_rd[2];            // [0]: the hi halves of a K-step's row (16-byte pieces 0..3), [1]: the lo halves (4..7)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = ((kk * 4 + fq) ^ (frow & 7)) << 4;
+        a_rd[kk] = (wm * (BM / WM) + frow) * kRowBytes + sw;
+        b1_rd[kk] = A_BYTES + (wn * (CMID / WN) + frow) * kRowBytes + sw;
+        a_rd2[kk] = (wm2 * (BM / P2M) + frow) * kRowBytes + sw;
+        b2_rd[kk] = T_BYTES + (wn2 * COLS2 + frow) * kRowBytes + sw;
+    }
+    f32x4 acc1[MF][NF1];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF1; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int nk = 9 * KC;
+    int cc = 0, kw = 0, kh = 0, issued = 0, ibuf = 0;
+    set_tap(0, 0);
+    auto issue_next = [&]() {
+        unsigned char* sa = smem + ibuf * STAGE + wave * A_IT * 8 * kRowBytes;
+        unsigned char* sb = smem + ibuf * STAGE + A_BYTES + wave * B_IT * 8 * kRowBytes;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) glds16(in_rsrc, a_voff[i], cc * kRowBytes, sa + i * 8 * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16(w1_rsrc, w_voff[i], issued * kRowBytes, sb + i * 8 * kRowBytes);
+        if (++kw == 3) {
+            kw = 0;
+            if (++kh == 3) { kh = 0; ++cc; }
+        }
+        set_tap(kh, kw);
+        ++issued;
+        ibuf ^= 1;
+    };
+    // shortcut rows of output tile t: requested early (tile 0 underneath the whole 3x3 phase), as raw [8 hi][8 lo] bits
+    RowAddr ra[MF2];
+    {
+        PixWalk pw;
+        pw.init(m0 + wm2 * (BM / P2M) + frow, HW, W);
+        const PixWalk first = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < MF2; ++i) {
+            const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
+            ra[i] = row_addr_at(d2, m < Mg ? pw : first, W, H, G2.H_res, G2.W_res, G2.out_off, G2.out_bstride, G2.res_off, G2.res_bstride);
+            if (i + 1 < MF2) pw.advance(16, H, W);
+        }
+    }
+    const bool has_res = d2.residual != nullptr;
+    f32x8 rpre[MF2][NF2 / 2];
+    auto prefetch_res = [&](int t, int jj) {
+#pragma unroll
+        for (int i = 0; i < MF2; ++i) {
+            const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
+            const char* p = x3_addr(d2.residual, ra[i].rbase, n);          // rows past the end were clamped to row 0: a valid address
+            rpre[i][jj].lo = *(const f32x4*)p;
+            rpre[i][jj].hi = *(const f32x4*)(p + 64);
+        }
+    };
+    if (has_res) {
+#pragma unroll
+        for (int jj = 0; jj < NF2 / 2; ++jj) prefetch_res(0, jj);
+    }
+    issue_next();
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < nk) issue_next();
+        const unsigned char* sbase = smem + (ks & 1) * STAGE;
+        xh8 ah[MF], al[MF], bh[NF1], bl[NF1];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            ah[i] = *(const xh8*)(sbase + a_rd[0] + i * 16 * kRowBytes);
+            al[i] = *(const xh8*)(sbase + a_rd[1] + i * 16 * kRowBytes);
+        }
+#pragma unroll
+        for (int j = 0; j < NF1; ++j) {
+            bh[j] = *(const xh8*)(sbase + b1_rd[0] + j * 16 * kRowBytes);
+            bl[j] = *(const xh8*)(sbase + b1_rd[1] + j * 16 * kRowBytes);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF1; ++j) {
+                acc1[i][j] = X3Half<DT>::mfma(bl[j], ah[i], acc1[i][j]);
+                acc1[i][j] = X3Half<DT>::mfma(bh[j], ah[i], acc1[i][j]);
+            }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF1; ++j) acc1[i][j] = X3Half<DT>::mfma(bh[j], al[i], acc1[i][j]);
+    }
+
+    // ---- hand-over: everyone is done with the ring; W2 tile 0 streams in while the intermediate tile is written as pre-split rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int w2_voff[W2_IT];
+#pragma unroll
+    for (int i = 0; i < W2_IT; ++i) w2_voff[i] = ((wave * W2_IT + i) * 8 + srow) * CMID * 4 + gchunk * 16;
+    auto stage_w2 = [&](int t) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int i = 0; i < W2_IT; ++i)
+                glds16(w2_rsrc, w2_voff[i], t * 128 * CMID * 4 + kc * kRowBytes,
+                       smem + T_BYTES + kc * 128 * kRowBytes + (wave * W2_IT + i) * 8 * kRowBytes);
+    };
+    stage_w2(0);
+    {
+        constexpr int COLS1 = CMID / WN;
+#pragma unroll
+        for (int jj = 0; jj < NF1 / 2; ++jj) {
+            const int n = wn * COLS1 + jj * 32 + fq * 8;              // 8 consecutive intermediate channels
+            float bias_v[8], scale_v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bias_v[e] = d1.bias ? d1.bias[n + e] : 0.0f;
+                scale_v[e] = (OSCALE && d1.out_scale) ? d1.out_scale[n + e] : 1.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int r = wm * (BM / WM) + i * 16 + frow;
+                xh8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = e < 4 ? acc1[i][2 * jj][e] : acc1[i][2 * jj + 1][e - 4];
+                    if constexpr (OSCALE) v = v * scale_v[e] + bias_v[e];
+                    else v = v + bias_v[e];
+                    if (d1.relu) v = fmaxf(v, 0.0f);
+                    v = X3Half<DT>::clamp(v);
+                    h[e] = (typename X3Half<DT>::half)v;
+                    l[e] = (typename X3Half<DT>::half)(v - (float)h[e]);
+                }
+                const int piece = (n & 31) >> 3;                      // 16-byte piece of the hi half of the 128-byte row; lo: + 4
+                unsigned char* row = smem + (n >> 5) * A_BYTES + r * kRowBytes;
+                *(xh8*)(row + ((piece ^ (r & 7)) << 4)) = h;
+                *(xh8*)(row + (((4 + piece) ^ (r & 7)) << 4)) = l;
+            }
+        }
+    }
+
+    // ---- phase 2: y tile = T (BM x CMID) * W2^T, 128 output channels at a time
+    const int n2_tiles = d2.C_out / 128;
+    for (int t = 0; t < n2_tiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // W2 tile t (and, for t = 0, T) is in LDS
+        asm volatile("" ::: "memory");
+        f32x4 acc2[MF2][NF2];
+#pragma unroll
+        for (int i = 0; i < MF2; ++i)
+#pragma unroll
+            for (int j = 0; j < NF2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            xh8 ah[MF2], al[MF2], bh[NF2], bl[NF2];
+#pragma unroll
+            for (int i = 0; i < MF2; ++i) {
+                ah[i] = *(const xh8*)(smem + kc * A_BYTES + a_rd2[0] + i * 16 * kRowBytes);
+                al[i] = *(const xh8*)(smem + kc * A_BYTES + a_rd2[1] + i * 16 * kRowBytes);
+            }
+#pragma unroll
+            for (int j = 0; j < NF2; ++j) {
+                bh[j] = *(const xh8*)(smem + kc * 128 * kRowBytes + b2_rd[0] + j * 16 * kRowBytes);
+                bl[j] = *(const xh8*)(smem + kc * 128 * kRowBytes + b2_rd[1] + j * 16 * kRowBytes);
+            }
+#pragma unroll
+            for (int i = 0; i < MF2; ++i)
+#pragma unroll
+                for (int j = 0; j < NF2; ++j) {
+                    acc2[i][j] = X3Half<DT>::mfma(bl[j], ah[i], acc2[i][j]);
+                    acc2[i][j] = X3Half<DT>::mfma(bh[j], ah[i], acc2[i][j]);
+                }
+#pragma unroll
+            for (int i = 0; i < MF2; ++i)
+#pragma unroll
+                for (int j = 0; j < NF2; ++j) acc2[i][j] = X3Half<DT>::mfma(bh[j], al[i], acc2[i][j]);
+        }
+        if (t + 1 < n2_tiles) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // everyone has read W2 tile t
+            asm volatile("" ::: "memory");
+            stage_w2(t + 1);                                           // streams in under the epilogue below
+        }
+        // per 8-channel group: scale + bias + shortcut, refill that group's shortcut registers for the next tile, ReLU + split + store
+#pragma unroll
+        for (int jj = 0; jj < NF2 / 2; ++jj) {
+            const int n = t * 128 + wn2 * COLS2 + jj * 32 + fq * 8;
+            float bias_v[8], scale_v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bias_v[e] = d2.bias ? d2.bias[n + e] : 0.0f;
+                scale_v[e] = (OSCALE && d2.out_scale) ? d2.out_scale[n + e] : 1.0f;
+            }
+            float outv[MF2][8];
+#pragma unroll
+            for (int i = 0; i < MF2; ++i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = e < 4 ? acc2[i][2 * jj][e] : acc2[i][2 * jj + 1][e - 4];
+                    if constexpr (OSCALE) outv[i][e] = a * scale_v[e] + bias_v[e];
+                    else outv[i][e] = a + bias_v[e];
+                }
+                if (has_res) {
+                    float r[8];
+                    x3_unpack<DT>(rpre[i][jj].lo, rpre[i][jj].hi, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) outv[i][e] += r[e];
+                }
+            }
+            if (has_res && t + 1 < n2_tiles) prefetch_res(t + 1, jj);
+#pragma unroll
+            for (int i = 0; i < MF2; ++i) {
+                const int m = m0 + wm2 * (BM / P2M) + i * 16 + frow;
+                if (m >= Mg) continue;
+                finish8_pre<DT>(d2, outv[i], n, ra[i].obase, false, f32x8());
+            }
+        }
+    }
+}
+
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember which devices a kernel has been configured
 // on (one bit per device ordinal; racing first calls both set the same value)
 struct DeviceOnce {
@@ -1645,6 +1940,44 @@ int launch_tail(gpp_conv_desc& d1, gpp_conv_desc& d2, hipStream_t st)
     kernel<<<dim3((unsigned)((rows + BM - 1) / BM)), dim3(256), lds, st>>>(d1, d2);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
+}
+
+template <int DT, int BM, int CMID>
+int launch_tail_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, hipStream_t st)
+{
+    constexpr int KC = CMID / 32;
+    constexpr int ring = 2 * (BM + CMID) * kRowBytes, phase2 = KC * BM * kRowBytes + KC * 128 * kRowBytes;
+    constexpr int lds = ring > phase2 ? ring : phase2;
+    static DeviceOnce once;
+    auto kernel = bottleneck_tail_x3_kernel<DT, BM, CMID>;
+    int rc = once.configure(kernel, lds);
+    if (rc != GPP_OK) return rc;
+    const gpp_conv_group& G = d1.groups[0];
+    const int64_t in_elems = G.in_off + (int64_t)(d1.batch - 1) * G.in_bstride + ((int64_t)G.H_in * G.W_in - 1) * d1.in_pitch + d1.C_in;
+    const int64_t w1_bytes = (int64_t)d1.weight_rows * 9 * CMID * 4, w2_bytes = (int64_t)d2.weight_rows * CMID * 4;
+    if (G.in_off < 0 || G.in_bstride < 0 || in_elems * 4 >= (1LL << 31) || w1_bytes >= (1LL << 31) || w2_bytes >= (1LL << 31))
+        return GPP_ERR_UNSUPPORTED;
+    d1.in_bytes = (int32_t)(in_elems * 4);
+    d1.weight_bytes = (int32_t)w1_bytes;
+    d2.weight_bytes = (int32_t)w2_bytes;
+    const int64_t rows = (int64_t)d1.batch * G.H_out * G.W_out;
+    kernel<<<dim3((unsigned)((rows + BM - 1) / BM)), dim3(256), lds, st>>>(d1, d2);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}
+
+// x3 types: C = 64 only (at C = 128 the intermediate tile and a W2 tile take 128 KB of LDS: one workgroup per CU)
+template <int DT>
+int dispatch_tail_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st)
+{
+    if (d1.C_in != 64) return GPP_ERR_UNSUPPORTED;
+    switch (tile_rows) {
+        case 96: return launch_tail_x3<DT, 96, 64>(d1, d2, st);
+        case 0:
+        case 128: return launch_tail_x3<DT, 128, 64>(d1, d2, st);
+        case 160: return launch_tail_x3<DT, 160, 64>(d1, d2, st);
+        default: return GPP_ERR_BAD_ARG;
+    }
 }
 
 template <int DT>

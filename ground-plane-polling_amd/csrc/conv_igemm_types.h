@@ -14,5 +14,7 @@ int gpp_conv_dispatch_bf16x3(gpp_conv_desc& d, hipStream_t st);
 int gpp_conv_dispatch_f16x3(gpp_conv_desc& d, hipStream_t st);
 int gpp_tail_dispatch_bf16(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st);
 int gpp_tail_dispatch_f16(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st);
+int gpp_tail_dispatch_bf16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st);
+int gpp_tail_dispatch_f16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st);
 
 #endif

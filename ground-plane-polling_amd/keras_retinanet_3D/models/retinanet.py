@@ -273,8 +273,12 @@ class RetinaNet3D(object):
         # whole step: none 1553, res3 only 1562, res2 + res3 1571 images/s (in isolation the fused res2 launch is no
         # faster than its two layers -- 122 us vs 36 + 80 -- but the step is: 69 MB less through HBM per block)
         fuse_tail = [int(v) for v in os.environ.get('GPP_FUSE_TAIL', '64,128').split(',') if v.strip() and int(v) > 0]
-        if self.esz == 4:
-            fuse_tail = []              # the fused tail keeps a 16-bit intermediate tile in LDS: 16-bit storage types only
+        if self.dtype in C.X3_TYPES:
+            # the x3 form of the fused tail (bottleneck_tail_x3_kernel): pre-split maps, C = 64 (res2) only -- at C = 128 its LDS
+            # footprint leaves one workgroup per CU
+            fuse_tail = [v for v in fuse_tail if v == 64] if x3_level >= 2 else []
+        elif self.esz == 4:
+            fuse_tail = []              # float32 operands: no fused tail
 
         def sub(fm, c0, nb):
             return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch, split=fm.split, half=fm.half)

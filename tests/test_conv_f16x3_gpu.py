@@ -277,3 +277,73 @@ def test_f16x3_arguments_are_validated():
     d = make(0)
     d.out_scale = None                                         # allowed: all ones (weights packed without a scale)
     assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == 0
+
+
+@pytest.mark.parametrize('tile_rows', [0, 96, 128, 160])
+@pytest.mark.parametrize('dtype', ['f16x3', 'bf16x3'])
+@pytest.mark.parametrize('B,H,W', [(2, 25, 31), (1, 7, 5), (3, 9, 40), (1, 101, 67)])
+def test_x3_bottleneck_tail_equals_the_two_layers(B, H, W, dtype, tile_rows):
+    """ gpp_bottleneck_tail for the x3 types on pre-split maps (bottleneck_tail_x3_kernel: 3x3 64 -> 64 + 1x1 64 -> 256 + shortcut +
+    ReLU in one launch, the intermediate tile kept in LDS as [32 hi | 32 lo] rows) reproduces the two separate launches bit for
+    bit, and never touches the intermediate map; the unfused pair is checked against float64 here too. """
+    cmid, cout = 64, 256
+    g = torch.Generator().manual_seed(H * W + B)
+    dev = torch.device('cuda')
+    a = torch.randn((B, H, W, cmid), generator=g)
+    k1 = torch.randn((3, 3, cmid, cmid), generator=g) * (2.0 / (9 * cmid)) ** 0.5
+    k1 = k1 * torch.pow(2.0, torch.randint(-3, 4, (cmid,), generator=g).float())[None, None, None, :]      # a different weight scale per channel
+    k2 = torch.randn((1, 1, cmid, cout), generator=g) * (2.0 / cmid) ** 0.5
+    b1, b2 = torch.randn((cmid,), generator=g) * 0.1, torch.randn((cout,), generator=g) * 0.1
+    sc = torch.randn((B, H, W, cout), generator=g)
+
+    def split_map(c, values=None):
+        m = C.FMap.empty(B, H, W, c, torch.float32, dev, split=True, half=dtype)
+        if values is not None:
+            m.write(values)
+        return m
+    amap, mid, rmap = split_map(cmid, a), split_map(cmid), split_map(cout, sc)
+    y_sep, y_fused = split_map(cout), split_map(cout)
+    w1, w2 = C.pack_weight(k1.numpy(), dtype, dev), C.pack_weight(k2.numpy(), dtype, dev)
+    s1 = C.out_scale_of(k1.numpy(), dev) if dtype == 'f16x3' else None
+    s2 = C.out_scale_of(k2.numpy(), dev) if dtype == 'f16x3' else None
+    b1d, b2d = b1.to(dev), b2.to(dev)
+    d1 = C.conv_desc([amap], [mid], w1, b1d, 3, 3, cmid, cmid, pad=(1, 1), relu=True, dtype=dtype, out_scale=s1)
+    d2 = C.conv_desc([mid], [y_sep], w2, b2d, 1, 1, cmid, cout, relu=True, residuals=[rmap], dtype=dtype, out_scale=s2)
+    C.run_conv(d1)
+    C.run_conv(d2)
+    want = y_sep.buf.clone()
+    mid_ref = reference64(amap.read().cpu(), k1, b1, 1, 1, 1, H, W, True, None)
+    ref = reference64(mid_ref.float(), k2, b2, 1, 0, 0, H, W, True, rmap.read().cpu())
+    got_sep = y_sep.read().double().cpu()
+    rms = float(ref.pow(2).mean().sqrt())
+    assert float((got_sep - ref).pow(2).mean().sqrt()) <= (1e-6 if dtype == 'f16x3' else 2e-5) * rms
+    d2f = C.conv_desc([mid], [y_fused], w2, b2d, 1, 1, cmid, cout, relu=True, residuals=[rmap], dtype=dtype, out_scale=s2)
+    mid.buf.fill_(float('nan'))                               # the fused launch must not depend on (or write) it
+    y_fused.buf.fill_(float('nan'))
+    hip.check(hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2f), tile_rows, hip.stream_ptr()), 'gpp_bottleneck_tail')
+    assert torch.equal(y_fused.buf.view(torch.int32), want.view(torch.int32))
+    assert torch.isnan(mid.buf).all()
+
+
+def test_x3_bottleneck_tail_needs_pre_split_maps_and_64_channels():
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 1, 9, 11
+
+    def layer_pair(cmid, split):
+        cout = 4 * cmid
+        mk = lambda c: C.FMap.empty(B, H, W, c, torch.float32, dev, split=split, half='f16x3')  # noqa: E731
+        k1 = torch.randn((3, 3, cmid, cmid), generator=g) * 0.05
+        k2 = torch.randn((1, 1, cmid, cout), generator=g) * 0.1
+        keep = [C.pack_weight(k1.numpy(), 'f16x3', dev), C.pack_weight(k2.numpy(), 'f16x3', dev), torch.zeros((cout,), device=dev),
+                C.out_scale_of(k1.numpy(), dev), C.out_scale_of(k2.numpy(), dev), mk(cmid), mk(cmid), mk(cout), mk(cout)]
+        d1 = C.conv_desc([keep[5]], [keep[6]], keep[0], keep[2], 3, 3, cmid, cmid, pad=(1, 1), relu=True, dtype='f16x3', out_scale=keep[3])
+        d2 = C.conv_desc([keep[6]], [keep[7]], keep[1], keep[2], 1, 1, cmid, cout, relu=True, residuals=[keep[8]], dtype='f16x3', out_scale=keep[4])
+        return d1, d2, keep
+    d1, d2, keep = layer_pair(64, False)                       # float32 maps: the fused form reads and writes pre-split rows only
+    assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 0, hip.stream_ptr()) == -4
+    d1, d2, keep2 = layer_pair(128, True)                      # C = 128: one workgroup per CU, not built
+    assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 0, hip.stream_ptr()) == -4
+    d1, d2, keep3 = layer_pair(64, True)
+    assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 64, hip.stream_ptr()) == -1
+    assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 0, hip.stream_ptr()) == 0
