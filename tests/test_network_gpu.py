@@ -179,6 +179,36 @@ def test_decode_overlap_does_not_change_results(monkeypatch):
             assert helpers.bits_equal(a, b)
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16x3'])
+def test_random_tiles_never_change_a_byte(dtype, monkeypatch):
+    """ GPP_TUNE_RANDOM: every conv layer (and fused tail) of the plan takes a RANDOM tile among the autotuner's candidates
+    (gpp_conv2d_tile_candidates) instead of the fastest one -- three different draws and the measured choice give identical output
+    bytes, head tensors included: the block tile never changes the K order of an output element (split-K is a rule of the layer) """
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    x = images(2, 200, 333, seed=4)
+    P = np.tile(P_inv[None].astype(np.float32), (2, 1, 1))
+    inputs = [x, P, np.tile(planes[None], (2, 1, 1))]
+
+    def run():
+        model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype=dtype)
+        out = model.predict_on_batch(inputs)
+        plan = model.plan_for(2, 200, 333, planes.shape[0], True)
+        return out + [plan.cls_logits.cpu().numpy(), plan.regression.cpu().numpy(), plan.regression_dim.cpu().numpy()], dict(plan.tuning)
+
+    want, tuned = run()
+    assert (want[2] > 0.05).sum() > 0
+    draws = []
+    for seed in (1, 2, 3):
+        monkeypatch.setenv('GPP_TUNE_RANDOM', str(seed))
+        got, tiles = run()
+        draws.append(tiles)
+        for a, b in zip(got, want):
+            assert helpers.bits_equal(a, b), seed
+    assert draws[0] != draws[1] or draws[1] != draws[2]            # the draws really differ
+    assert any(draws[0][k][0] != tuned[k][0] for k in tuned)
+
+
 def test_hip_graph_capture_replays_the_plan(monkeypatch):
     """ model.capture(plan): the whole plan, side-stream fork / join of the detection selection included, recorded into a
     HIP graph; replays give the eager results bit for bit on new inputs """
