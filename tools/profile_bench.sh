@@ -8,7 +8,7 @@ out=${1:-gpurun_out/prof}
 dt=${2:-f16x3}
 case $dt in bf16) code=1; gf=431.8;; f16) code=2; gf=431.8;; bf16x3) code=4; gf=431.8;; *) code=5; gf=431.8;; esac
 xin=""; if [ $code -ge 4 ]; then xin=", true"; fi
-fused="0,1"; if [ $code -ge 3 ]; then fused=""; fi
+fused="0,1"; if [ $code -eq 3 ]; then fused=""; fi; if [ $code -ge 4 ]; then fused="0"; fi      # x3 types: the res2 tails are fused, res3 is not
 mkdir -p $out
 export GPP_TUNE_CACHE=$GRAFT_REPO_ROOT/$out/tune_cache.json
 python3 bench.py --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --no-host-fed > $out/tuning_run.log 2>&1

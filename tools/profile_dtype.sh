@@ -10,7 +10,7 @@ python3 bench.py --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --dtype $dt --steps 6 --warmup 2 --no-cpu-baseline --no-f32-leg --no-host-fed > $out/bench_under_rocprof.log 2>&1
 grep '^{"metric"' $out/bench_under_rocprof.log > $out/bench_under_rocprof.json
 trace=$(find $out/trace -name '*kernel_trace.csv' | head -1)
-fused="0,1"; if [ "$dt" = "f32" ] || [ "$dt" = "bf16x3" ] || [ "$dt" = "f16x3" ]; then fused=""; fi
+fused="0,1"; if [ "$dt" = "f32" ]; then fused=""; fi; if [ "$dt" = "bf16x3" ] || [ "$dt" = "f16x3" ]; then fused="0"; fi
 python3 tools/trace_table.py "$trace" resnet50 "$fused" > $out/per_layer.txt
 tail -3 $out/per_layer.txt
 rm -rf $out/trace
