@@ -42,15 +42,21 @@ def backbone(backbone_name):
 
 
 def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, class_specific_filter=True,
-               orientation_specific_filter=False, dtype='bf16'):
+               orientation_specific_filter=False, dtype=None):
     """ Loads a RetinaNet-3D inference model (reference models/__init__.py:59-88).
 
     `convert` is accepted for signature compatibility: every model this function returns already
     contains the decode / NMS / ground-plane-polling stages (`retinanet_bbox`, retinanet.py:359-422).
-    `dtype`: 'bf16' (default) | 'f16' = 16-bit storage and MFMA operands, float32 accumulation; 'f32' = float32 storage
-    and operands (the reference's floatx, /root/reference/keras_retinanet_3D/utils/image.py:47); 'bf16x3' = float32 storage,
-    each product as three bf16 matrix products (~2^-16 relative error per product, three times the bf16 matrix work).
+    `dtype` (not in the reference; None = the environment's GPP_DTYPE, else 'f16x3'):
+        'f16x3' (default)  float32-sized storage, every float32 product as three IEEE-half matrix products: the fastest type whose
+                           detections, plane indices and 3-D corners stay within BASELINE's tolerance of the float32 path
+        'f32'              float32 storage and operands (the reference's floatx, /root/reference/keras_retinanet_3D/utils/image.py:47)
+        'bf16x3'           three bf16 products per float32 product (~2^-16): same detections and planes, corners off by millimetres
+        'f16' | 'bf16'     16-bit storage and MFMA operands, float32 accumulation: 2.4x faster, a few percent of the detections differ
     """
+    import os
+    if dtype is None:
+        dtype = os.environ.get('GPP_DTYPE', 'f16x3')
     from . import weights as W
     from .retinanet import RetinaNet3D
     b = backbone(backbone_name)

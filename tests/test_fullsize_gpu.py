@@ -150,7 +150,7 @@ def test_conv_stack_at_402x1333_matches_the_storage_oracle():
     """ whole bf16 stack against the oracle in 16-bit storage mode and against the float32 oracle, bars of
     tests/test_network_gpu.py::test_conv_stack_matches_oracle, at the BASELINE size """
     img, P_inv, planes = _inputs(2, '10')
-    model = models.load_model('synthetic:1234', backbone_name='resnet50')
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='bf16')
     _, _, _, plan = _run(model, img, P_inv, planes)
     got = _heads(plan, 2)
     weights = W.synthetic_weights('resnet50', 1234)

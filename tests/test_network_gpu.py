@@ -44,7 +44,7 @@ def unfuse(reg, n_base=12):
 
 @pytest.fixture(scope='module')
 def model50():
-    return models.load_model('synthetic:1234', backbone_name='resnet50')
+    return models.load_model('synthetic:1234', backbone_name='resnet50', dtype='bf16')
 
 
 @pytest.mark.parametrize('batch,h,w', [(2, 96, 160), (1, 127, 211)])
@@ -73,7 +73,7 @@ def test_conv_stack_matches_oracle(model50, batch, h, w):
 @pytest.mark.parametrize('backbone', ['resnet50', 'resnet101', 'resnet152'])
 def test_predict_on_batch_end_to_end(backbone, oracle_lib):
     batch, h, w = 2, 128, 224
-    model = models.load_model('synthetic:7', backbone_name=backbone)
+    model = models.load_model('synthetic:7', backbone_name=backbone, dtype='bf16')
     img = images(batch, h, w, seed=3)
     planes = synthetic.load_plane_database('1k').astype(np.float32)
     _, P_inv = synthetic.synthetic_calibration()
@@ -140,7 +140,7 @@ def test_model_loaded_from_a_keras_h5_checkpoint(model50, tmp_path):
         pytest.skip(str(e))
     path = str(tmp_path / 'resnet50_inference.h5')
     W.save_weights(path, W.synthetic_weights('resnet50', 1234))
-    model = models.load_model(path, backbone_name='resnet50', convert=False)
+    model = models.load_model(path, backbone_name='resnet50', convert=False, dtype='bf16')
     batch, h, w = 2, 96, 160
     img = images(batch, h, w, seed=21)
     planes = synthetic.load_plane_database('100').astype(np.float32)
@@ -161,13 +161,13 @@ def test_decode_overlap_does_not_change_results(monkeypatch):
     _, P_inv = synthetic.synthetic_calibration()
     x = images(2, 160, 256, seed=9)
     P = np.tile(P_inv[None].astype(np.float32), (2, 1, 1))
-    model = models.load_model('synthetic:1234', backbone_name='resnet50')
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='bf16')
     got = model.predict_on_batch([x, P, np.tile(planes[None], (2, 1, 1))])
     plan = model.plan_for(2, 160, 256, planes.shape[0], True)
     assert plan.decode_overlap and [op[3] for op in plan.ops if op[3].startswith('filtered')] == \
         ['filtered_detections/candidates', 'filtered_detections/select', 'filtered_detections']
     monkeypatch.setenv('GPP_DECODE_OVERLAP', '0')
-    serial = models.load_model('synthetic:1234', backbone_name='resnet50')
+    serial = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='bf16')
     want = serial.predict_on_batch([x, P, np.tile(planes[None], (2, 1, 1))])
     assert not serial.plan_for(2, 160, 256, planes.shape[0], True).decode_overlap
     assert (got[2] > 0.05).sum() > 0
@@ -213,7 +213,7 @@ def test_hip_graph_capture_replays_the_plan(monkeypatch):
     """ model.capture(plan): the whole plan, side-stream fork / join of the detection selection included, recorded into a
     HIP graph; replays give the eager results bit for bit on new inputs """
     monkeypatch.setenv('GPP_AUTOTUNE', '0')
-    model = models.load_model('synthetic:1234', backbone_name='resnet50')
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='bf16')
     planes = synthetic.load_plane_database('100').astype(np.float32)
     _, P_inv = synthetic.synthetic_calibration()
     P = np.tile(P_inv[None].astype(np.float32), (2, 1, 1))
@@ -235,7 +235,7 @@ def test_orientation_specific_filter_through_the_model(monkeypatch):
     """ models.load_model(..., orientation_specific_filter=True): same conv stack, per-orientation decode; checked against the
     oracle's decode of the GPU's own head tensors, then polling against the C oracle """
     monkeypatch.setenv('GPP_AUTOTUNE', '0')
-    model = models.load_model('synthetic:1234', backbone_name='resnet50', orientation_specific_filter=True)
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', orientation_specific_filter=True, dtype='bf16')
     planes = synthetic.load_plane_database('100').astype(np.float32)
     _, P_inv = synthetic.synthetic_calibration()
     x = images(2, 160, 256, seed=5)

@@ -133,7 +133,7 @@ def test_gpu_preprocessing_is_bit_identical_to_the_host_path():
     import numpy as np
     from keras_retinanet_3D import models
     from keras_retinanet_3D.utils import image, synthetic
-    model = models.load_model('synthetic:3', backbone_name='resnet50')
+    model = models.load_model('synthetic:3', backbone_name='resnet50', dtype='bf16')
     frames = np.stack([synthetic.synthetic_image(seed=s) for s in (1, 2)])
     planes = synthetic.load_plane_database('10').astype(np.float32)
     scale = image.compute_resize_scale(frames.shape[1:])

@@ -6,7 +6,7 @@ import numpy as np, torch
 from keras_retinanet_3D import models
 from keras_retinanet_3D.utils import synthetic
 from keras_retinanet_3D.utils.pipeline import FramePipeline
-m = models.load_model('synthetic:1234', backbone_name='resnet50')
+m = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='bf16')
 B = 8
 frames = (np.random.default_rng(5).integers(0, 2, size=(B, 375, 1242, 3)) * 255).astype(np.uint8)      # as bench.py's host-fed legs
 planes = np.tile(synthetic.load_plane_database('1k').astype(np.float32)[None], (B, 1, 1))

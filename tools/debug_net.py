@@ -11,7 +11,7 @@ B, H, Wd = 2, 96, 160
 rng = np.random.default_rng(96)
 img = rng.integers(0, 256, size=(B, H, Wd, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32)
 w = W.synthetic_weights('resnet50', 1234)
-m = models.load_model(w, backbone_name='resnet50')
+m = models.load_model(w, backbone_name='resnet50', dtype='bf16')
 _, P_inv = synthetic.synthetic_calibration()
 plan = m.stage_inputs([img, np.tile(P_inv[None], (B, 1, 1)), synthetic.load_plane_database('10')])
 m.run_plan(plan)

@@ -19,7 +19,7 @@ from keras_retinanet_3D.utils.pipeline import FramePipeline   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 B = 8
-model = models.load_model('synthetic:1234')
+model = models.load_model('synthetic:1234', dtype='bf16')
 planes = synthetic.load_plane_database('1k').astype(np.float32)
 frames = (np.random.default_rng(5).integers(0, 2, size=(B, 375, 1242, 3)) * 255).astype(np.uint8)
 _, P_inv = synthetic.synthetic_calibration(1333.0 / 1242.0)
