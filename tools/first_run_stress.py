@@ -40,7 +40,7 @@ def worker(rank, world, port, dtype, tag):
     lo, hi = D.shard_range(batch, rank, world)
     dbg = None
     if hasattr(hip.lib(), 'gpp_poll_debug_buffer'):
-        dbg = torch.full(((hi - lo) * 100, 32), float('nan'), dtype=torch.float32, device='cuda')
+        dbg = torch.full(((hi - lo) * 100, 256, 8), float('nan'), dtype=torch.float32, device='cuda')      # per lane: csrc/poll.hip, GPP_POLL_DEBUG
         hip.lib().gpp_poll_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
     if use_dist:
         D.ShardedModel(model).predict_on_batch(inputs)
@@ -67,13 +67,11 @@ def worker(rank, world, port, dtype, tag):
             line = 'WRONG PLANE tag {} rank {} image {} detection {}: gpu {} (residual {:.6f}) oracle {} (residual {:.6f})'.format(
                 tag, rank, lo + b, d, best[b, d], res[b, d] * 6, want[3][b, d], want[2][b, d] * 6)
             if dbg is not None:
-                q = dbg[b * 100 + d].cpu().numpy()
-                line += '\n    wave hashes {} wave rmin {} wave imin {} merged rmin {} imin {} i100 {} vmax {}'.format(
-                    q[0:4].tolist(), q[4:8].tolist(), q[8:12].view(np.int32).tolist(), q[12], q[13:14].view(np.int32)[0],
-                    q[14:15].view(np.int32)[0], q[15:16].view(np.int32)[0])
-                line += '\n    winner lane {} saw plane {} residual {} votes {} zc {}; canonical plane now {}'.format(
-                    q[23:24].view(np.int32)[0], q[16:20].tolist(), q[20], q[21], q[22],
-                    plan.poll_ws.cpu().numpy().view(np.float32).reshape(-1, 4)[b * 1000 + best[b, d]].tolist())
+                q = dbg[b * 100 + d].cpu().numpy()                                   # (256 lanes, 8): rmin, imin, i100, level, exec lo / hi, iterations, tid
+                act = q[:, 4:6].view(np.uint32)
+                line += '\n    lane states: active masks {}, iterations {}, lanes whose level is below the maximum {}'.format(
+                    sorted(set('%08x%08x' % (hi_, lo_) for lo_, hi_ in act.tolist())), sorted(set(q[:, 6].view(np.int32).tolist())),
+                    int((q[:, 3].view(np.int32) < q[:, 3].view(np.int32).max()).sum()))
             print(line, flush=True)
         print('dumped ' + path, flush=True)
     else:
