@@ -130,6 +130,23 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int voffset,
 
 constexpr int kOutOfRange = (int)0x80000000;
 
+#ifndef GPP_DMA_SPREAD
+#define GPP_DMA_SPREAD 1
+#endif
+#ifndef GPP_X3_PRIO
+#define GPP_X3_PRIO 1
+#endif
+#ifndef GPP_X3_WB
+#define GPP_X3_WB 0
+#endif
+#ifndef GPP_X3_BEARLY
+#define GPP_X3_BEARLY 0
+#endif
+#ifndef GPP_X3_TAP_EARLY
+#define GPP_X3_TAP_EARLY 0
+#endif
+constexpr bool kSpreadDma = GPP_DMA_SPREAD != 0;
+
 // Diagnostic build only (-DGPP_STAMPS, tools/bench_conv.py stamps): wave 0 of every workgroup writes the 100 MHz
 // real-time counter at five points into a buffer of its own (handed in through the otherwise unused zero_page
 // field when reserved bit 4 is set).  No output depends on it; the production build contains none of this.
@@ -145,7 +162,9 @@ constexpr int kOutOfRange = (int)0x80000000;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
         GPP_STAMP(4);                                                                                         \
     } while (0)
+#define GPP_ABL(flag) if (!(flag))
 #else
+#define GPP_ABL(flag)
 #define GPP_STAMP(k) do { } while (0)
 #define GPP_STAMP_END() do { } while (0)
 #endif
@@ -680,6 +699,18 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         // zero-length descriptor (dropped by the range check) and the look-ahead reads hit a buffer
         // nobody uses: no branches inside the interleaved region.
         static_assert(STAGES == 2, "pipelined loop: two buffers");
+        // kSpreadDma: every read of stage k lies between the barriers of steps k-1 and k, so the buffer of stage k+2 (= that of stage k) may
+        // be written anywhere between the barriers of steps k and k+1.  Issuing all of a stage's LDS-DMA in the phase right after the
+        // barrier made that phase as long as the CU's tile-fill rate allows (~38 cycles per 1 KB piece: profiles/r2/fill_rate_microbench.txt)
+        // while the other phases ran at matrix speed with the vector-memory path idle (in-kernel phase stamps, profiles/r3/x3_phase_stamps.txt).
+        // The weight rows (L2-hot: every workgroup reads the same ones) therefore go out one phase LATER -- phase A / phase 0 of the next step,
+        // with that step's saved descriptor and offset -- and still land before the barrier that publishes them; the activation rows (which
+        // may come from HBM) keep the early slot.  Same bytes into the same LDS addresses before the same barrier: results unchanged.
+        // Only the three-phase x3 loop does this: there the late pieces have phase B to land.  In the two-phase 16-bit loop the barrier
+        // follows phase 0 directly and the late pieces were waited for (measured: bf16 regression tower 0.57 -> 0.52 of its peak).
+        // (and not the 4 x 1-wavefront 128 x 160 tile, MF = 2: its two groups per phase leave the late pieces no room; 327 -> 338 us with them)
+        constexpr bool SPREAD = kSpreadDma && kX3<DT> && MF >= 4;
+        constexpr int C_PIECES = SPREAD ? A_IT : PER_STAGE;
         // the zero-length descriptor of the tail is built from a SCALAR select of its record count: selecting between two
         // whole descriptors made the compiler carry them in VGPRs and wrap every LDS-DMA of the loop in a waterfall loop
         // (v_readfirstlane / v_cmp / s_and_saveexec / s_cbranch_execnz, four per K-step)
@@ -710,6 +741,14 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             // it, so the four sets take 96 registers (as in the 16-bit loop) and the body needs no second copy.  One barrier per
             // 3 MF NF MFMAs; the DMA of stage k+2 has two phases to land.
             static_assert(XIN, "the pipelined bf16x3 loop reads pre-split activation rows");
+            // which weight fragments group g of a phase fetches: spread over all MF groups, or (GPP_X3_BEARLY) one per group from the first
+            // group on, so that the last of them has more than a group's time to arrive before the next phase's first MFMA needs all NF
+#if GPP_X3_BEARLY
+            constexpr int BPG = (NF + MF - 1) / MF;
+            auto BJ0 = [](int g) { return g * BPG < NF ? g * BPG : NF; };
+#else
+            auto BJ0 = [](int g) { return g * NF / MF; };
+#endif
             xh8 ah[MF], al[MF], bh[NF], bl[NF];
 #pragma unroll
             for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 0, in_rsrc, w_rsrc, cc * kRowBytes, ks0 * kRowBytes);
@@ -717,18 +756,34 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            // (kSpreadDma) the weight rows of a stage go out one phase after its activation rows, those of stage 1 in phase A of step 0
+            __amdgpu_buffer_rsrc_t rw_late;
+            int so_w_late;
             {
                 const bool live = issued < nk;
                 const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
 #pragma unroll
-                for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 1, ra, rw, cc * kRowBytes, (ks0 + issued) * kRowBytes);
+                for (int idx = 0; idx < C_PIECES; ++idx) issue_one(idx, 1, ra, rw, cc * kRowBytes, (ks0 + issued) * kRowBytes);
+                rw_late = rw;
+                so_w_late = __builtin_amdgcn_readfirstlane((ks0 + issued) * kRowBytes);
                 if (live) advance_tap();
             }
 #pragma unroll
             for (int i = 0; i < MF; ++i) ah[i] = *(const xh8*)(smem + a_rd[0] + i * 16 * kRowBytes);
 #pragma unroll
             for (int j = 0; j < NF; ++j) bl[j] = *(const xh8*)(smem + b_rd[1] + j * 16 * kRowBytes);
-            if (NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+            if (GPP_X3_PRIO && NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#ifdef GPP_STAMPS
+            // diagnostic build, reserved bit 5: wavefront (reserved >> 8) & 7 of the first 64 workgroups sums, in scalar registers, the
+            // real-time counter differences of the three phases and of the wait + barrier over its K-steps (the counter is read at
+            // the phase boundaries and consumed where lgkmcnt is 0 anyway); five words per workgroup at the end
+            // ablations of the same build (timing only, the results are wrong): bit 6 no LDS-DMA in the loop, bit 7 no LDS reads in phase C,
+            // bit 11 none in phases A / B, bit 12 no static priority
+            const bool abl_dma = d.reserved & 64, abl_rdc = d.reserved & 128, abl_rdab = d.reserved & 2048;
+            if (NW == 8 && (d.reserved & 4096)) __builtin_amdgcn_s_setprio(0);
+            const bool stamping = (d.reserved & 32) && blockIdx.x < 64 && wave == ((d.reserved >> 8) & 7);
+            unsigned long long t_top = 0, t_a = 0, t_b = 0, t_bar = 0, t_prev = 0, sum_a = 0, sum_b = 0, sum_w = 0, sum_c = 0;
+#endif
             for (int ks = 0; ks < nk; ++ks) {
                 const int cur = ks & 1;
                 const unsigned char* scur = smem + cur * STAGE;
@@ -736,44 +791,99 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 const bool live = issued < nk;
                 const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
                 const int so_a = __builtin_amdgcn_readfirstlane(cc * kRowBytes), so_w = __builtin_amdgcn_readfirstlane((ks0 + issued) * kRowBytes);
+#ifdef GPP_STAMPS
+                if (stamping) t_top = __builtin_amdgcn_s_memrealtime();
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- phase A: hi * wlo, fetch whi
 #pragma unroll
                 for (int g = 0; g < MF; ++g) {
+                    if constexpr (SPREAD) {
 #pragma unroll
-                    for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) bh[j] = *(const xh8*)(scur + b_rd[0] + j * 16 * kRowBytes);
+                        for (int idx = A_IT + g * (B_IT - GPP_X3_WB) / MF; idx < A_IT + (g + 1) * (B_IT - GPP_X3_WB) / MF; ++idx) GPP_ABL(abl_dma) issue_one(idx, cur ^ 1, rw_late, rw_late, 0, so_w_late);
+                    }
+#pragma unroll
+                    for (int j = BJ0(g); j < BJ0(g + 1); ++j) GPP_ABL(abl_rdab) bh[j] = *(const xh8*)(scur + b_rd[0] + j * 16 * kRowBytes);
 #pragma unroll
                     for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bl[j], ah[g], acc[g][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#ifdef GPP_STAMPS
+                if (stamping) t_a = __builtin_amdgcn_s_memrealtime();
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 // ---- phase B: hi * whi, fetch lo
 #pragma unroll
                 for (int g = 0; g < MF; ++g) {
-                    al[g] = *(const xh8*)(scur + a_rd[1] + g * 16 * kRowBytes);
+                    if constexpr (SPREAD && GPP_X3_WB > 0) {
+                        if (g < GPP_X3_WB) GPP_ABL(abl_dma) issue_one(A_IT + B_IT - GPP_X3_WB + g, cur ^ 1, rw_late, rw_late, 0, so_w_late);
+                    }
+                    GPP_ABL(abl_rdab) al[g] = *(const xh8*)(scur + a_rd[1] + g * 16 * kRowBytes);
 #pragma unroll
                     for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bh[j], ah[g], acc[g][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#ifdef GPP_STAMPS
+                if (stamping) t_b = __builtin_amdgcn_s_memrealtime();
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef GPP_STAMPS
+                if (stamping) {                 // every counter read so far has returned (lgkmcnt 0): the previous step's wait and phase C, this step's A and B
+                    if (ks > 0) { sum_w += t_bar - t_prev; sum_c += t_top - t_bar; }
+                    sum_a += t_a - t_top;
+                    sum_b += t_b - t_a;
+                    t_prev = t_b;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#ifdef GPP_STAMPS
+                if (stamping) t_bar = __builtin_amdgcn_s_memrealtime();
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- phase C: lo * whi, stage k+2 goes out, fetch hi and wlo of stage k+1
 #pragma unroll
                 for (int g = 0; g < MF; ++g) {
 #pragma unroll
-                    for (int idx = g * PER_STAGE / MF; idx < (g + 1) * PER_STAGE / MF; ++idx) issue_one(idx, cur, ra, rw, so_a, so_w);
-                    ah[g] = *(const xh8*)(snxt + a_rd[0] + g * 16 * kRowBytes);
+                    for (int idx = g * C_PIECES / MF; idx < (g + 1) * C_PIECES / MF; ++idx) GPP_ABL(abl_dma) issue_one(idx, cur, ra, rw, so_a, so_w);
+                    GPP_ABL(abl_rdc) ah[g] = *(const xh8*)(snxt + a_rd[0] + g * 16 * kRowBytes);
 #pragma unroll
-                    for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) bl[j] = *(const xh8*)(snxt + b_rd[1] + j * 16 * kRowBytes);
+                    for (int j = BJ0(g); j < BJ0(g + 1); ++j) GPP_ABL(abl_rdc) bl[j] = *(const xh8*)(snxt + b_rd[1] + j * 16 * kRowBytes);
+#if GPP_X3_TAP_EARLY
+                    if (g == MF - 1) {              // the next tap's offsets, computed beside the last group's MFMAs (branch-free: past the last stage the
+                        rw_late = rw;               // descriptors are zero-length, whatever the offsets)
+                        so_w_late = so_w;
+                        ++kw;
+                        const bool ww = kw == d.KW;
+                        kw = ww ? 0 : kw;
+                        kh += ww ? 1 : 0;
+                        const bool wh = kh == d.KH;
+                        kh = wh ? 0 : kh;
+                        cc += wh ? 1 : 0;
+                        set_tap(kh, kw);
+                        ++issued;
+                    }
+#endif
 #pragma unroll
                     for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bh[j], al[g], acc[g][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#if !GPP_X3_TAP_EARLY
+                rw_late = rw;
+                so_w_late = so_w;
                 if (live) advance_tap();
+#endif
             }
             if (NW == 8) __builtin_amdgcn_s_setprio(0);
+#ifdef GPP_STAMPS
+            if (stamping && lane == 0) {
+                unsigned long long* o = (unsigned long long*)d.zero_page + (1 << 19) + blockIdx.x * 8;
+                o[0] = sum_a; o[1] = sum_b; o[2] = sum_w; o[3] = sum_c; o[4] = (unsigned long long)nk;
+            }
+#endif
         } else {
         frag a0[MF], b0[NF], a1[MF], b1[NF];
         // prologue: stage 0 -> buffer 0, wait, stage 1 -> buffer 1, fragments kk=0 of step 0
@@ -783,11 +893,15 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        __amdgpu_buffer_rsrc_t rw_late;
+        int so_w_late;
         {
             const bool live = issued < nk;
             const __amdgpu_buffer_rsrc_t ra = tail_rsrc(d.in, d.in_bytes, live), rw = tail_rsrc(d.weight, d.weight_bytes, live);
 #pragma unroll
-            for (int idx = 0; idx < PER_STAGE; ++idx) issue_one(idx, 1, ra, rw, cc * kRowBytes, (ks0 + issued) * kRowBytes);
+            for (int idx = 0; idx < C_PIECES; ++idx) issue_one(idx, 1, ra, rw, cc * kRowBytes, (ks0 + issued) * kRowBytes);
+            rw_late = rw;
+            so_w_late = __builtin_amdgcn_readfirstlane((ks0 + issued) * kRowBytes);
             if (live) advance_tap();
         }
         load_frags(a0, b0, 0, 0);
@@ -813,6 +927,10 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
             // ---- phase 0
 #pragma unroll
             for (int g = 0; g < MF; ++g) {
+                if constexpr (SPREAD) {
+#pragma unroll
+                    for (int idx = A_IT + g * B_IT / MF; idx < A_IT + (g + 1) * B_IT / MF; ++idx) issue_one(idx, cur ^ 1, rw_late, rw_late, 0, so_w_late);
+                }
                 a1[g] = *(const frag*)(scur + a_rd[1] + g * 16 * kRowBytes);
 #pragma unroll
                 for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) b1[j] = *(const frag*)(scur + b_rd[1] + j * 16 * kRowBytes);
@@ -829,7 +947,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
 #pragma unroll
             for (int g = 0; g < MF; ++g) {
 #pragma unroll
-                for (int idx = g * PER_STAGE / MF; idx < (g + 1) * PER_STAGE / MF; ++idx) issue_one(idx, cur, ra, rw, so_a, so_w);
+                for (int idx = g * C_PIECES / MF; idx < (g + 1) * C_PIECES / MF; ++idx) issue_one(idx, cur, ra, rw, so_a, so_w);
                 a0[g] = *(const frag*)(snxt + a_rd[0] + g * 16 * kRowBytes);
 #pragma unroll
                 for (int j = g * NF / MF; j < (g + 1) * NF / MF; ++j) b0[j] = *(const frag*)(snxt + b_rd[0] + j * 16 * kRowBytes);
@@ -837,6 +955,8 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 for (int j = 0; j < NF; ++j) acc[g][j] = E::mfma(b1[j], a1[g], acc[g][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            rw_late = rw;
+            so_w_late = so_w;
             if (live) advance_tap();         // a_voff for the next issue changes only after this step's DMA is out
         }
         if (NW == 8) __builtin_amdgcn_s_setprio(0);

@@ -197,6 +197,90 @@ if __name__ == '__main__':
         bench('res4 2b 3x3 256->256 t96128', B, [(26, 84)], 256, 256, 3, tile=96128, iters=20)
         bench('res5 2b 3x3 512->512 t64128', B, [(13, 42)], 512, 512, 3, tile=64128, iters=20)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'x3time':
+        # the big head / FPN layers of the x3 types on pre-split maps, one tile each (A/B of library builds: GPP_LIB=...)
+        dev = torch.device('cuda')
+        dtype = sys.argv[3] if len(sys.argv) > 3 else 'f16x3'
+        reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+        layers = []
+        for name, shp, cin, cout, k, tile, f32 in (('reg 3x3 512->512', PYR, 512, 512, 3, 1256256, False), ('towers_0 3x3 512->896', PYR, 512, 896, 3, 2256256, False),
+                                                   ('cls 3x3 256->256', PYR, 256, 256, 3, 1192256, False), ('P3 3x3 512->512', PYR[:1], 512, 512, 3, 1192256, False),
+                                                   ('reg_ops 3x3 512->144', PYR, 512, 144, 3, 1128160, True), ('dim 3x3 128->128', PYR, 128, 128, 3, 1192128, False)):
+            total = sum(h * w for h, w in shp)
+            wk = (torch.randn((k, k, cin, cout)) * 0.02).numpy()
+            w = C.pack_weight(wk, dtype, dev)
+            sc = C.out_scale_of(wk, dev) if dtype == 'f16x3' else None
+            bias = torch.zeros((cout,), device=dev)
+            ib = torch.empty((B, total, cin), device=dev); ob = torch.empty((B, total, cout), device=dev)
+            ins, outs, off = [], [], 0
+            for h, wd in shp:
+                ins.append(C.FMap(ib, B, h, wd, cin, off=off * cin, bstride=total * cin, split=True, half=dtype))
+                outs.append(C.FMap(ob, B, h, wd, cout, off=off * cout, bstride=total * cout, split=not f32, half=dtype))
+                ins[-1].write(torch.randn((B, h, wd, cin), device=dev) * 0.5)
+                off += h * wd
+            d = C.conv_desc(ins, outs, w, bias, k, k, cin, cout, pad=(k // 2, k // 2), relu=not f32, dtype=dtype, tile_hint=tile, out_scale=sc, out_f32=f32)
+            layers.append((name, tile, d, C.conv_flops(d), (ib, ob, w, bias, sc)))
+        best = {}
+        for rep in range(reps + 1):
+            for name, tile, d, fl, _ in layers:
+                for _ in range(2):
+                    C.run_conv(d)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    C.run_conv(d)
+                e1.record()
+                torch.cuda.synchronize()
+                if rep:
+                    best.setdefault(name, []).append(e0.elapsed_time(e1) / 20 * 1e3)
+        tot = 0.0
+        for name, tile, d, fl, _ in layers:
+            v = sorted(best[name])
+            med = v[len(v) // 2]
+            tot += med
+            print('%-24s %s tile %7d: median %7.1f us  min %7.1f  (%.0f TFLOP/s of float32 products)' % (name, dtype, tile, med, v[0], fl / med / 1e6))
+        print('sum of medians %.1f us' % tot)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == 'x3stamps':
+        # phases of the pipelined x3 loop (library built with -DGPP_STAMPS): per K-step, for one wavefront of the first 64 workgroups,
+        # phase A (hi * wlo), phase B (hi * whi), wait + barrier, phase C (lo * whi + the LDS-DMA of the stage after next)
+        import numpy as np
+        dev = torch.device('cuda')
+        dtype = sys.argv[3] if len(sys.argv) > 3 else 'f16x3'
+        # optional 4th argument: comma-separated ablation masks of the diagnostic build (64 no LDS-DMA, 128 no LDS reads in phase C,
+        # 2048 none in phases A / B, 4096 no static priority; sums combine them) -- timing only
+        masks = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else [0]
+        for name, shp, cin, cout, k, tile in (('reg 3x3 512->512', PYR, 512, 512, 3, 1192256), ('cls 3x3 256->256', PYR, 256, 256, 3, 1192256)):
+            total = sum(h * w for h, w in shp)
+            x = torch.randn((B, total, cin), device=dev) * 0.5
+            wk = (torch.randn((k, k, cin, cout)) * 0.02).numpy()
+            w = C.pack_weight(wk, dtype, dev)
+            sc = C.out_scale_of(wk, dev) if dtype == 'f16x3' else None
+            bias = torch.zeros((cout,), device=dev)
+            ib = torch.empty((B, total, cin), device=dev); ob = torch.empty((B, total, cout), device=dev)
+            ins, outs, off = [], [], 0
+            for h, wd in shp:
+                ins.append(C.FMap(ib, B, h, wd, cin, off=off * cin, bstride=total * cin, split=True, half=dtype))
+                outs.append(C.FMap(ob, B, h, wd, cout, off=off * cout, bstride=total * cout, split=True, half=dtype))
+                ins[-1].write(x[:, off:off + h * wd].reshape(B, h, wd, cin))
+                off += h * wd
+            for mask, wv in [(m, v) for m in masks for v in ((0, 1, 4, 5) if len(masks) > 1 else range(8))]:
+                d = C.conv_desc(ins, outs, w, bias, k, k, cin, cout, pad=(k // 2, k // 2), relu=True, dtype=dtype, tile_hint=tile, diag=32 + (wv << 8) + mask, out_scale=sc)
+                stamps = torch.zeros(((1 << 16) + 1024, 8), dtype=torch.int64, device=dev)
+                d.zero_page = stamps.data_ptr()
+                for _ in range(3):
+                    C.run_conv(d)
+                torch.cuda.synchronize()
+                stamps.zero_()
+                C.run_conv(d)
+                torch.cuda.synchronize()
+                st = stamps.cpu().numpy()[(1 << 16):].reshape(-1)[:64 * 8].reshape(64, 8).astype(np.float64)
+                st = st[st[:, 4] > 0]
+                per = st[:, :4] * 0.01 / st[:, 4:5]
+                m = per.mean(axis=0)
+                print('%-18s %s tile %d ablation %4d wavefront %d: per K-step %.3f us = A %.3f + B %.3f + wait, barrier %.3f + C %.3f   (%d workgroups, %d K-steps)' %
+                      (name, dtype, tile, mask, wv, m.sum(), m[0], m[1], m[2], m[3], len(st), int(st[0, 4])))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == 'kstamps':
         # inside a K-step of the plain (non-pipelined) loop, library built with -DGPP_STAMPS
         import numpy as np
