@@ -206,7 +206,7 @@ class RetinaNet3D(object):
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
-    def _tail(self, plan, nm, a, y, shortcut):
+    def _tail(self, plan, nm, a, y, shortcut, join=False):
         """ branch2b (3x3) + branch2c (1x1, + shortcut, ReLU) of one bottleneck as ONE launch
         (gpp_bottleneck_tail): the intermediate map never reaches HBM.  Bit-identical to the two layers. """
         d1 = self._desc(plan, 'res{}_branch2b'.format(nm), [a], [a], 3, pad=(1, 1), relu=True)       # its `out` is never written
@@ -214,7 +214,7 @@ class RetinaNet3D(object):
         plan.keep += [d1, d2]
         t = TailDesc(ctypes.addressof(d1), ctypes.addressof(d2), 0, 0)
         name = 'res{}_branch2b+2c'.format(nm)
-        plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2))
+        plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2), join=join)
         plan.io[name] = ([a], [y], [shortcut])
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
@@ -224,6 +224,7 @@ class RetinaNet3D(object):
         # split-K partial tiles of the deep-K layers with a tiny per-image grid (res5 branch2b, P5..P7); one workspace per
         # stream lane (concurrent launches must not share partial tiles), sized from the descriptors at the end of _build
         head_lanes = os.environ.get('GPP_HEAD_LANES', '0') != '0'
+        br1_lane = os.environ.get('GPP_BR1_LANE', '1') != '0'         # measured +0.4 % on the f16x3 step (same box, alternating)
         plan.conv_descs, plan.ws_need = [], {}
 
         def fmap(h, w, c, dtype=None):
@@ -304,18 +305,24 @@ class RetinaNet3D(object):
                 for rec in blocks:
                     nm, stride = rec['nm'], rec['stride']
                     a_, y_ = sub(rec['a'], c0, nb), sub(rec['y'], c0, nb)
+                    # the projection shortcut of a stage's first block is independent of branch2a / 2b: on a side stream it runs beside them
+                    # and branch2c (or the fused tail) joins it (GPP_BR1_LANE=0: serial, behind branch2a)
+                    side = br1_lane and rec['sc'] is not None
+                    if side:
+                        sc_ = sub(rec['sc'], c0, nb)
+                        self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=1)
                     self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True)
-                    if rec['sc'] is not None:
+                    if rec['sc'] is not None and not side:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride)
-                    else:
+                    elif rec['sc'] is None:
                         sc_ = xs
                     if rec['b'] is None:
-                        self._tail(plan, nm, a_, y_, sc_)
+                        self._tail(plan, nm, a_, y_, sc_, join=side)
                     else:
                         b_ = sub(rec['b'], c0, nb)
                         self._conv(plan, 'res{}_branch2b'.format(nm), [a_], [b_], 3, pad=(1, 1), relu=True)
-                        self._conv(plan, 'res{}_branch2c'.format(nm), [b_], [y_], 1, relu=True, residuals=[sc_])
+                        self._conv(plan, 'res{}_branch2c'.format(nm), [b_], [y_], 1, relu=True, residuals=[sc_], join=side)
                     xs = y_
             feats.append(x)
         _, C3, C4, C5 = feats
@@ -350,8 +357,10 @@ class RetinaNet3D(object):
         pyr, P = pyramid(512)
         T5 = smap(C5.H, C5.W, 512)
         # P5 and the P6 -> ReLU -> P7 chain are small launches (a few dozen tiles) independent of the C4 / C3 chain:
-        # with GPP_HEAD_LANES=1 they run on the side streams underneath the big P4 / P3 launches
-        l_p5, l_p6 = (1, 2) if head_lanes else (0, 0)
+        # they run on the side streams underneath the C4_reduced / P4 launches (182 workgroups each: 74 CUs idle), joined by the
+        # fused first tower layer (GPP_FPN_LANES=0: serial)
+        fpn_lanes = head_lanes or os.environ.get('GPP_FPN_LANES', '1') != '0'      # measured +0.8 % on the f16x3 step
+        l_p5, l_p6 = (1, 2) if fpn_lanes else (0, 0)
         self._conv(plan, 'C5_reduced', [C5], [T5], 1)
         self._conv(plan, 'P5', [T5], [P[2]], 3, pad=(1, 1), lane=l_p5)
         self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]), lane=l_p6)
@@ -398,6 +407,7 @@ class RetinaNet3D(object):
         # underneath the dimension tower; the full decode of the <= 100 survivors joins when every head is done.
         overlap = os.environ.get('GPP_DECODE_OVERLAP', '1') != '0' and not head_lanes and not self.osf
         plan.decode_overlap = overlap
+        plan.side_lanes = {'fpn': fpn_lanes, 'branch1': br1_lane}
 
         def dim_tower():
             dim_t = tower('pyramid_regression_dim', 128, slice_of(wide_maps, 768, 128), lane=l_dim)

@@ -16,6 +16,7 @@ head tensors, which pins the plumbing between the stages.
 """
 import numpy as np
 import pytest
+import torch
 
 import helpers
 from oracle import decode_np, net_torch, polling_np
@@ -176,6 +177,41 @@ def test_decode_overlap_does_not_change_results(monkeypatch):
     for _ in range(3):                       # back-to-back runs reuse the side stream and the workspace
         again = model.predict_on_batch([x, P, np.tile(planes[None], (2, 1, 1))])
         for a, b in zip(again, want):
+            assert helpers.bits_equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', ['f16x3', 'bf16'])
+def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
+    """ default plan: the projection shortcut of every stage's first block runs on a side stream beside branch2a / 2b, P5 and the
+    P6 -> ReLU -> P7 chain beside C4_reduced / P4.  GPP_BR1_LANE=0 GPP_FPN_LANES=0: everything on one stream.  Disjoint outputs,
+    explicit joins: identical bytes, head tensors and pyramid included, also on repeated runs. """
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    x = images(3, 200, 333, seed=12)
+    P = np.tile(P_inv[None].astype(np.float32), (3, 1, 1))
+    inputs = [x, P, np.tile(planes[None], (3, 1, 1))]
+
+    def run(n=1):
+        model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype=dtype)
+        outs = []
+        for _ in range(n):
+            out = model.predict_on_batch(inputs)
+            plan = model.plan_for(3, 200, 333, planes.shape[0], True)
+            outs.append(out + [plan.cls_logits.cpu().numpy(), plan.regression.cpu().numpy(), plan.regression_dim.cpu().numpy()] +
+                        [plan.features[k].buf.contiguous().view(torch.uint8).cpu().numpy() for k in ('C3', 'C4', 'C5', 'P3')])
+        return outs, plan
+
+    lanes, plan = run(4)
+    assert plan.side_lanes == {'fpn': True, 'branch1': True}
+    names = [op[3] for op in plan.ops]
+    assert names.index('res3a_branch1') < names.index('res3a_branch2a')          # forked before the chain it runs beside
+    monkeypatch.setenv('GPP_BR1_LANE', '0')
+    monkeypatch.setenv('GPP_FPN_LANES', '0')
+    serial, splan = run()
+    assert splan.side_lanes == {'fpn': False, 'branch1': False}
+    assert (serial[0][2] > 0.05).sum() > 0
+    for got in lanes:
+        for a, b in zip(got, serial[0]):
             assert helpers.bits_equal(a, b)
 
 
