@@ -201,9 +201,9 @@ class RetinaNet3D(object):
         return d
 
     def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0, lane=0,
-              join=False):
+              join=False, sync=False):
         d = self._desc(plan, name, inputs, outputs, K, stride, pad, relu, residuals, out_f32, lane)
-        plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join)
+        plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join, sync=sync)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
     def _tail(self, plan, nm, a, y, shortcut, join=False):
@@ -372,7 +372,10 @@ class RetinaNet3D(object):
                    pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]), lane=l_p6)
         T4 = smap(C4.H, C4.W, 512)
         self._conv(plan, 'C4_reduced', [C4], [T4], 1, residuals=[T5])          # + UpsampleLike(P5, C4), fused
-        self._conv(plan, 'P4', [T4], [P[1]], 3, pad=(1, 1))
+        # P4 (182 workgroups of 192 x 256: 71 % of the CUs) only feeds the towers: behind P5 on its side stream (re-forked: it needs T4), it
+        # runs beside C3_reduced / P3 (GPP_P4_LANE=0: serial)
+        p4_lane = 1 if (fpn_lanes and os.environ.get('GPP_P4_LANE', '1') != '0') else 0
+        self._conv(plan, 'P4', [T4], [P[1]], 3, pad=(1, 1), lane=p4_lane, sync=bool(p4_lane))
         T3 = smap(C3.H, C3.W, 512)
         self._conv(plan, 'C3_reduced', [C3], [T3], 1, residuals=[T4])          # + UpsampleLike(P4, C3), fused
         self._conv(plan, 'P3', [T3], [P[0]], 3, pad=(1, 1))
@@ -407,7 +410,7 @@ class RetinaNet3D(object):
         # underneath the dimension tower; the full decode of the <= 100 survivors joins when every head is done.
         overlap = os.environ.get('GPP_DECODE_OVERLAP', '1') != '0' and not head_lanes and not self.osf
         plan.decode_overlap = overlap
-        plan.side_lanes = {'fpn': fpn_lanes, 'branch1': br1_lane}
+        plan.side_lanes = {'fpn': fpn_lanes, 'branch1': br1_lane, 'p4': bool(p4_lane)}
 
         def dim_tower():
             dim_t = tower('pyramid_regression_dim', 128, slice_of(wide_maps, 768, 128), lane=l_dim)

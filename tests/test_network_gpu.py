@@ -183,7 +183,7 @@ def test_decode_overlap_does_not_change_results(monkeypatch):
 @pytest.mark.parametrize('dtype', ['f16x3', 'bf16'])
 def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
     """ default plan: the projection shortcut of every stage's first block runs on a side stream beside branch2a / 2b, P5 and the
-    P6 -> ReLU -> P7 chain beside C4_reduced / P4.  GPP_BR1_LANE=0 GPP_FPN_LANES=0: everything on one stream.  Disjoint outputs,
+    P6 -> ReLU -> P7 chain beside C4_reduced, P4 (behind P5) beside C3_reduced / P3.  GPP_BR1_LANE=0 GPP_FPN_LANES=0: everything on one stream.  Disjoint outputs,
     explicit joins: identical bytes, head tensors and pyramid included, also on repeated runs. """
     planes = synthetic.load_plane_database('100').astype(np.float32)
     _, P_inv = synthetic.synthetic_calibration()
@@ -202,13 +202,13 @@ def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
         return outs, plan
 
     lanes, plan = run(4)
-    assert plan.side_lanes == {'fpn': True, 'branch1': True}
+    assert plan.side_lanes == {'fpn': True, 'branch1': True, 'p4': True}
     names = [op[3] for op in plan.ops]
     assert names.index('res3a_branch1') < names.index('res3a_branch2a')          # forked before the chain it runs beside
     monkeypatch.setenv('GPP_BR1_LANE', '0')
     monkeypatch.setenv('GPP_FPN_LANES', '0')
     serial, splan = run()
-    assert splan.side_lanes == {'fpn': False, 'branch1': False}
+    assert splan.side_lanes == {'fpn': False, 'branch1': False, 'p4': False}
     assert (serial[0][2] > 0.05).sum() > 0
     for got in lanes:
         for a, b in zip(got, serial[0]):
