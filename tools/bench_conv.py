@@ -216,7 +216,7 @@ if __name__ == '__main__':
             for h, wd in shp:
                 ins.append(C.FMap(ib, B, h, wd, cin, off=off * cin, bstride=total * cin, split=True, half=dtype))
                 outs.append(C.FMap(ob, B, h, wd, cout, off=off * cout, bstride=total * cout, split=not f32, half=dtype))
-                ins[-1].write(torch.randn((B, h, wd, cin), device=dev) * 0.5)
+                ins[-1].write(torch.randn((B, h, wd, cin), device=dev) * 0.5 * float(os.environ.get('X3TIME_ASCALE', '1')))      # (0: what the data costs)
                 off += h * wd
             d = C.conv_desc(ins, outs, w, bias, k, k, cin, cout, pad=(k // 2, k // 2), relu=not f32, dtype=dtype, tile_hint=tile, out_scale=sc, out_f32=f32)
             layers.append((name, tile, d, C.conv_flops(d), (ib, ob, w, bias, sc)))
