@@ -455,6 +455,7 @@ def main():
                                            'identical detection sets, identical plane index, 3-D corners within 1e-3 m (BASELINE.json north_star)'),
                        'parity_bars_met': bars_met,
                        'resident_batches_rotated': RESIDENT_BATCHES,
+                       'side_stream_launches': dict(getattr(plan, 'side_lanes', {}), decode=bool(getattr(plan, 'decode_overlap', False))),
                        'multi_gpu_diagnosis': per_rank,
                        'other_types_same_frames': other_legs or None,
                        'host_fed_synchronous_images_per_s_incl_pcie_and_gpu_preprocessing': pcie_rate,
