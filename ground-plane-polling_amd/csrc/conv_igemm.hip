@@ -174,7 +174,7 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 // One list for the autotuner below and for gpp_conv2d_tile_candidates (tests draw tiles at random from it).
 static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                              1128128, 1192128, 1128256, 1192256, 256256, 1256256,
-                             128160, 192160, 1192160, 1128160, 2256256,
+                             128160, 192160, 1192160, 1128160, 2256256, 1192096,
                              128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
 // (the loader-wavefront form of round 2, tile codes 3064128 ..., measured 1.5 - 2x slower on every layer it was built for
 // (profiles/r2/ring_kernel.txt), is no longer part of the library)
@@ -196,6 +196,7 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
     if (bn == 256 && desc->dtype == GPP_F32) return false;
     if ((tile == 128256 || tile == 192256) && !is_x3(desc->dtype)) return false;
     if (bn == 160 && (desc->C_out + 159) / 160 * 160 >= (desc->C_out + 127) / 128 * 128) return false;   // only where it cuts the N padding
+    if (bn == 96 && (desc->C_out + 95) / 96 * 96 >= (desc->C_out + 127) / 128 * 128) return false;       // likewise (the 96 logits)
     if (tile == 2256256 && (desc->C_out < 384 || desc->C_out % 256 != 128 || rows < 256 * 16)) return false;   // dual-shape grid: C_out = 256 k + 128
     return true;
 }

@@ -1985,6 +1985,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                     case 1192256: return launch<DT, 192, 256, 2, 4, 2, true>(d, st);
                     case 1192160: return launch<DT, 192, 160, 4, 1, 2, true>(d, st);
                     case 1128160: return launch<DT, 128, 160, 4, 1, 2, true>(d, st);
+                    case 1192096: return launch<DT, 192, 96, 4, 1, 2, true>(d, st);          // 96-channel outputs (the classification logits)
                     case 2256256: return launch_dual<DT>(d, st);            // 256 x 256 tiles + 512 x 128 tiles for the last 128 columns, one grid
                     case 512:
                     case 256256:
@@ -2007,6 +2008,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                             case 1192128: return launch<DT, 192, 128, 2, 2, 2, true, true>(d, st);
                             case 1128128: return launch<DT, 128, 128, 2, 2, 2, true, true>(d, st);
                             case 1128160: return launch<DT, 128, 160, 4, 1, 2, true, true>(d, st);      // 144-channel outputs: three-phase loop on a 4 x 1 layout
+                            case 1192096: return launch<DT, 192, 96, 4, 1, 2, true, true>(d, st);       // 96-channel outputs, same layout
                             case 2256256: return launch_dual<DT>(d, st);      // C_out = 256 k + 128: the dual-shape grid
                             default: break;
                         }
@@ -2017,7 +2019,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                 }
                 switch (d.tile_hint) {
                     case 256: case 1128128: case 1192128: case 1128256: case 1192256: case 1192160: case 1128160: case 2256256: case 512: case 256256: case 1256256:
-                    case 192256: case 128256:
+                    case 192256: case 128256: case 1192096:
                         return GPP_ERR_UNSUPPORTED;
                     default: return GPP_ERR_BAD_ARG;
                 }

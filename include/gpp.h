@@ -150,10 +150,10 @@ typedef struct gpp_conv_desc {
     int32_t n_groups;
     int32_t tile_hint;              /* 0 = library heuristic; BM*1000 + BN forces a block tile (64..224 x 64/128, 128/192 x 160,
                                        256256), + 1000000 = the software-pipelined main loop (128128, 192128, 128256, 192256,
-                                       192160, 128160), 2256256 = 256256 plus 512 x 128 tiles for the last 128 columns in one grid
+                                       192160, 128160, 192096), 2256256 = 256256 plus 512 x 128 tiles for the last 128 columns in one grid
                                        (C_out = 256 k + 128 only); legacy codes 64 / 128 / 256 / 512; anything else: GPP_ERR_BAD_ARG.
                                        GPP_BF16X3: the plain tiles, 128256 / 192256 / 256256 (8 wavefronts), and on a pre-split input
-                                       map (x3_split & GPP_X3_IN) the pipelined 1128128, 1192128, 1128256, 1192256, 1256256, 1128160 and 2256256.
+                                       map (x3_split & GPP_X3_IN) the pipelined 1128128, 1192128, 1128256, 1192256, 1256256, 1128160, 1192096 and 2256256.
                                        See gpp_conv2d_autotune */
     int32_t reserved;               /* must be 0 (anything else: GPP_ERR_BAD_ARG).  Only the diagnostic -DGPP_STAMPS build of the
                                        library (make stamps; tools/bench_conv.py) reads it: bit 0 skip the tile loads, bit 1 skip

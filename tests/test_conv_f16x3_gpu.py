@@ -26,7 +26,7 @@ from test_conv_f32_gpu import reference64
 pytestmark = pytest.mark.gpu
 
 PLAIN_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128, 128160, 128256, 192256, 256256]
-PIPE_TILES = [1128128, 1192128, 1128256, 1192256, 1256256, 1128160]
+PIPE_TILES = [1128128, 1192128, 1128256, 1192256, 1256256, 1128160, 1192096]
 
 
 def held(t):
@@ -189,6 +189,45 @@ def test_f16x3_dual_shape_grid(cin, cout, relu):
             rms = float(ref.pow(2).mean().sqrt())
             assert float((got - ref).pow(2).mean().sqrt()) <= 1.5 * (3e-8 * (9 * cin) ** 0.5 + 1e-7) * rms
     assert torch.equal(results[0], results[1])
+
+
+@pytest.mark.parametrize('dtype', ['f16x3', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('cout', [96, 180])
+def test_the_96_column_tile_on_the_logits_shape(dtype, cout):
+    """ tile code 1192096 (192 x 96, 4 x 1 wavefronts, the pipelined loop): float32 outputs of 96 / 180 channels over ragged pyramid
+    levels -- the bits of the plain 128 x 128 tile (and of the pipelined 192 x 128 one) """
+    g = torch.Generator().manual_seed(cout)
+    dev = torch.device('cuda')
+    B, cin, shapes = 2, 128, [(25, 31), (13, 16), (7, 8), (4, 4), (2, 2)]
+    total = sum(h * w for h, w in shapes)
+    x3 = dtype in C.X3_TYPES
+    tdt = torch.float32 if x3 else C.torch_dtype(dtype)
+    xbuf = torch.empty((B, total, cin), dtype=tdt, device=dev)
+    k = torch.randn((3, 3, cin, cout), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    w = C.pack_weight(k.numpy(), dtype, dev)
+    scale = C.out_scale_of(k.numpy(), dev) if dtype == 'f16x3' else None
+    b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    ins, off = [], 0
+    for h, wd in shapes:
+        fm = C.FMap(xbuf, B, h, wd, cin, off=off * cin, bstride=total * cin, split=x3, half=dtype if x3 else 'bf16x3')
+        fm.write(torch.randn((B, h, wd, cin), generator=g))
+        ins.append(fm)
+        off += h * wd
+    tiles, count = (ctypes.c_int * 32)(), ctypes.c_int(0)
+    probe = C.conv_desc(ins, ins, w, b, 3, 3, cin, cout, pad=(1, 1), dtype=dtype, out_f32=True, out_scale=scale)
+    hip.check(hip.lib().gpp_conv2d_tile_candidates(ctypes.byref(probe), tiles, 32, ctypes.byref(count)), 'gpp_conv2d_tile_candidates')
+    assert 1192096 in list(tiles[:count.value])                      # offered to the autotuner where it cuts the N padding
+    results = []
+    for tile in (128128, 1192128, 1192096):
+        o = torch.full((B, total, cout), float('nan'), dtype=torch.float32, device=dev)
+        outs, off = [], 0
+        for h, wd in shapes:
+            outs.append(C.FMap(o, B, h, wd, cout, off=off * cout, bstride=total * cout))
+            off += h * wd
+        C.run_conv(C.conv_desc(ins, outs, w, b, 3, 3, cin, cout, pad=(1, 1), relu=False, dtype=dtype, tile_hint=tile, out_f32=True, out_scale=scale))
+        assert torch.isfinite(o).all()
+        results.append(o.view(torch.int32).cpu())
+    assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
 
 
 def test_f16x3_range_activations_beyond_the_half_range_are_clamped_not_inf():

@@ -371,7 +371,7 @@ def test_relu_on_a_pre_split_map():
     assert torch.equal(dst.read().cpu(), torch.relu(_x3_round(x)))
 
 
-X3_PIPE_TILES = [1128128, 1192128, 1128256, 1192256, 1256256, 1128160]
+X3_PIPE_TILES = [1128128, 1192128, 1128256, 1192256, 1256256, 1128160, 1192096]
 
 
 @pytest.mark.parametrize('case', ['3x3_wide', 'bottleneck_2c', '3x3_s2_tfsame', 'deepK', '1x1'])

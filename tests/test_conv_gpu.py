@@ -175,7 +175,8 @@ def test_split_k_matches_torch_fp32(case, split):
 
 ALL_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
              1128128, 1192128, 1128256, 1192256, 256256,
-             128160, 192160, 1192160, 1128160]        # N-remainder tiles (4 x 1 wavefronts, 160 columns)
+             128160, 192160, 1192160, 1128160,        # N-remainder tiles (4 x 1 wavefronts, 160 columns)
+             1192096]                                 # ... and 96 columns
 
 
 def _layer(name, dtype='bf16', workspace=False):
