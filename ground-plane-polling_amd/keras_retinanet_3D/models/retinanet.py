@@ -206,7 +206,7 @@ class RetinaNet3D(object):
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join, sync=sync)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
-    def _tail(self, plan, nm, a, y, shortcut, join=False):
+    def _tail(self, plan, nm, a, y, shortcut, join=False, lane=0):
         """ branch2b (3x3) + branch2c (1x1, + shortcut, ReLU) of one bottleneck as ONE launch
         (gpp_bottleneck_tail): the intermediate map never reaches HBM.  Bit-identical to the two layers. """
         d1 = self._desc(plan, 'res{}_branch2b'.format(nm), [a], [a], 3, pad=(1, 1), relu=True)       # its `out` is never written
@@ -214,7 +214,7 @@ class RetinaNet3D(object):
         plan.keep += [d1, d2]
         t = TailDesc(ctypes.addressof(d1), ctypes.addressof(d2), 0, 0)
         name = 'res{}_branch2b+2c'.format(nm)
-        plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2), join=join)
+        plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2), join=join, lane=lane)
         plan.io[name] = ([a], [y], [shortcut])
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
@@ -224,6 +224,8 @@ class RetinaNet3D(object):
         # split-K partial tiles of the deep-K layers with a tiny per-image grid (res5 branch2b, P5..P7); one workspace per
         # stream lane (concurrent launches must not share partial tiles), sized from the descriptors at the end of _build
         head_lanes = os.environ.get('GPP_HEAD_LANES', '0') != '0'
+        # res3 .. res5 run as two half batches, the second half on a side stream beside the first (GPP_HALF_LANES="" for whole batches)
+        half_stages = set(int(v) for v in os.environ.get('GPP_HALF_LANES', '1,2,3').split(',') if v.strip()) if B >= 2 else set()
         br1_lane = os.environ.get('GPP_BR1_LANE', '1') != '0'         # measured +0.4 % on the f16x3 step (same box, alternating)
         plan.conv_descs, plan.ws_need = [], {}
 
@@ -299,31 +301,38 @@ class RetinaNet3D(object):
                 blocks.append(rec)
                 x = rec['y']
             chunk = max(1, min(B, int(env_chunks.split(',')[stage]))) if env_chunks else B
-            for c0 in range(0, B, chunk):
-                nb = min(chunk, B - c0)
-                xs = sub(xin, c0, nb)
-                for rec in blocks:
+            # GPP_HALF_LANES (default "1,2,3" = res3, res4, res5): the stage as two half batches, the second half on a side stream beside
+            # the first.  A launch of these stages fills the 256 CUs 0.7 - 1.4 times and is bound by tile fills and first-touch latency;
+            # two independent chains in flight overlap one's prologue / epilogue / barrier waits with the other's main loop (f16x3 step,
+            # same box, alternating: 775 -> 793 images/s).  An image's result does not depend on its batch (section 4.4): same bytes.
+            # The halves stay apart until the FPN's first layer joins them; the per-block shortcut stream is not used inside them.
+            halves = stage in half_stages and B >= 2 and not env_chunks
+            # (three parts on three streams, measured: 801 against 811 images/s for two)
+            parts = [(B // 2, B - B // 2, 1), (0, B // 2, 0)] if halves else [(c0, min(chunk, B - c0), 0) for c0 in range(0, B, chunk)]
+            xs_of = {c0: sub(xin, c0, nb) for c0, nb, _ in parts}
+            for rec, (c0, nb, ln) in ([(r, p) for r in blocks for p in parts] if halves else [(r, p) for p in parts for r in blocks]):
+                    xs = xs_of[c0]
                     nm, stride = rec['nm'], rec['stride']
                     a_, y_ = sub(rec['a'], c0, nb), sub(rec['y'], c0, nb)
                     # the projection shortcut of a stage's first block is independent of branch2a / 2b: on a side stream it runs beside them
                     # and branch2c (or the fused tail) joins it (GPP_BR1_LANE=0: serial, behind branch2a)
-                    side = br1_lane and rec['sc'] is not None
+                    side = br1_lane and rec['sc'] is not None and not halves
                     if side:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=1)
-                    self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True)
+                    self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True, lane=ln)
                     if rec['sc'] is not None and not side:
                         sc_ = sub(rec['sc'], c0, nb)
-                        self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride)
+                        self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=ln)
                     elif rec['sc'] is None:
                         sc_ = xs
                     if rec['b'] is None:
-                        self._tail(plan, nm, a_, y_, sc_, join=side)
+                        self._tail(plan, nm, a_, y_, sc_, join=side, lane=ln)
                     else:
                         b_ = sub(rec['b'], c0, nb)
-                        self._conv(plan, 'res{}_branch2b'.format(nm), [a_], [b_], 3, pad=(1, 1), relu=True)
-                        self._conv(plan, 'res{}_branch2c'.format(nm), [b_], [y_], 1, relu=True, residuals=[sc_], join=side)
-                    xs = y_
+                        self._conv(plan, 'res{}_branch2b'.format(nm), [a_], [b_], 3, pad=(1, 1), relu=True, lane=ln)
+                        self._conv(plan, 'res{}_branch2c'.format(nm), [b_], [y_], 1, relu=True, residuals=[sc_], join=side, lane=ln)
+                    xs_of[c0] = y_
             feats.append(x)
         _, C3, C4, C5 = feats
         plan.features = {'stem': plan.stem_out, 'C2': feats[0], 'C3': C3, 'C4': C4, 'C5': C5}
@@ -361,7 +370,7 @@ class RetinaNet3D(object):
         # fused first tower layer (GPP_FPN_LANES=0: serial)
         fpn_lanes = head_lanes or os.environ.get('GPP_FPN_LANES', '1') != '0'      # measured +0.8 % on the f16x3 step
         l_p5, l_p6 = (1, 2) if fpn_lanes else (0, 0)
-        self._conv(plan, 'C5_reduced', [C5], [T5], 1)
+        self._conv(plan, 'C5_reduced', [C5], [T5], 1, join=bool(half_stages))
         self._conv(plan, 'P5', [T5], [P[2]], 3, pad=(1, 1), lane=l_p5)
         self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]), lane=l_p6)
         R6 = smap(shapes[3][0], shapes[3][1], 512)
@@ -410,7 +419,7 @@ class RetinaNet3D(object):
         # underneath the dimension tower; the full decode of the <= 100 survivors joins when every head is done.
         overlap = os.environ.get('GPP_DECODE_OVERLAP', '1') != '0' and not head_lanes and not self.osf
         plan.decode_overlap = overlap
-        plan.side_lanes = {'fpn': fpn_lanes, 'branch1': br1_lane, 'p4': bool(p4_lane)}
+        plan.side_lanes = {'fpn': fpn_lanes, 'branch1': br1_lane, 'p4': bool(p4_lane), 'half_batch_stages': sorted(half_stages)}
 
         def dim_tower():
             dim_t = tower('pyramid_regression_dim', 128, slice_of(wide_maps, 768, 128), lane=l_dim)

@@ -182,7 +182,8 @@ def test_decode_overlap_does_not_change_results(monkeypatch):
 
 @pytest.mark.parametrize('dtype', ['f16x3', 'bf16'])
 def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
-    """ default plan: the projection shortcut of every stage's first block runs on a side stream beside branch2a / 2b, P5 and the
+    """ default plan: res3 .. res5 as two half batches (1 + 2 images here) on two streams; the projection shortcut of res2's first block
+    on a side stream beside branch2a / 2b, P5 and the
     P6 -> ReLU -> P7 chain beside C4_reduced, P4 (behind P5) beside C3_reduced / P3.  GPP_BR1_LANE=0 GPP_FPN_LANES=0: everything on one stream.  Disjoint outputs,
     explicit joins: identical bytes, head tensors and pyramid included, also on repeated runs. """
     planes = synthetic.load_plane_database('100').astype(np.float32)
@@ -202,13 +203,15 @@ def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
         return outs, plan
 
     lanes, plan = run(4)
-    assert plan.side_lanes == {'fpn': True, 'branch1': True, 'p4': True}
+    assert plan.side_lanes == {'fpn': True, 'branch1': True, 'p4': True, 'half_batch_stages': [1, 2, 3]}
     names = [op[3] for op in plan.ops]
-    assert names.index('res3a_branch1') < names.index('res3a_branch2a')          # forked before the chain it runs beside
+    assert names.index('res2a_branch1') < names.index('res2a_branch2a')          # forked before the chain it runs beside
+    assert names.count('res4b_branch2b') == 2                                    # one launch per half batch
     monkeypatch.setenv('GPP_BR1_LANE', '0')
     monkeypatch.setenv('GPP_FPN_LANES', '0')
+    monkeypatch.setenv('GPP_HALF_LANES', '')
     serial, splan = run()
-    assert splan.side_lanes == {'fpn': False, 'branch1': False, 'p4': False}
+    assert splan.side_lanes == {'fpn': False, 'branch1': False, 'p4': False, 'half_batch_stages': []}
     assert (serial[0][2] > 0.05).sum() > 0
     for got in lanes:
         for a, b in zip(got, serial[0]):
@@ -446,7 +449,8 @@ def check_every_layer(backbone, dtype, fuse_next, batch, h, w, monkeypatch):
     (tests/test_fullsize_gpu.py runs the same check at the BASELINE size 402x1333.) """
     import torch
     from keras_retinanet_3D.models.retinanet import OP_CONV, OP_MAXPOOL, OP_RELU, OP_STEM, OP_STEM_POOL, OP_TAIL
-    model50 = models.load_model('synthetic:1234', backbone_name=backbone, dtype=dtype)
+    monkeypatch.setenv('GPP_HALF_LANES', '')          # one launch per layer over the whole batch (the half-batch plan: same kernels on image sub-ranges,
+    model50 = models.load_model('synthetic:1234', backbone_name=backbone, dtype=dtype)      # identical bytes: test_side_stream_lanes_do_not_change_results)
     weights = W.synthetic_weights(backbone, 1234)
     img = images(batch, h, w, seed=11)
     planes = synthetic.load_plane_database('10').astype(np.float32)

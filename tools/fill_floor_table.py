@@ -7,6 +7,7 @@ between, as inside the network).
     python tools/fill_floor_table.py [dtype] [backbone]              (on the GPU box) """
 import ctypes
 import os
+os.environ.setdefault('GPP_HALF_LANES', '')          # one launch per layer (whole batch)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -10,9 +10,9 @@ case $dt in bf16) code=1; gf=431.8;; f16) code=2; gf=431.8;; bf16x3) code=4; gf=
 xin=""; if [ $code -ge 4 ]; then xin=", true"; fi
 fused="0,1"; if [ $code -eq 3 ]; then fused=""; fi; if [ $code -ge 4 ]; then fused="0"; fi      # x3 types: the res2 tails are fused, res3 is not
 mkdir -p $out
-# the per-layer table names the convolution launches by their order in the trace: profiled on ONE stream (the default plan runs the
-# projection shortcuts and P5 / P6 / P7 on side streams, ~1 % faster on the step; the dominant kernel is not touched by that)
-export GPP_FPN_LANES=0 GPP_BR1_LANE=0
+# the per-layer table names the convolution launches by their order in the trace: profiled on ONE stream (the default plan runs res3-res5
+# as two half batches on two streams and P5 / P6 / P7 / P4 on side streams, ~4 % faster on the step; the dominant kernel is not touched by that)
+export GPP_FPN_LANES=0 GPP_BR1_LANE=0 GPP_HALF_LANES=
 export GPP_TUNE_CACHE=$GRAFT_REPO_ROOT/$out/tune_cache.json
 python3 bench.py --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --no-host-fed > $out/tuning_run.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --no-f32-leg --no-host-fed > $out/bench_under_rocprof.log 2>&1
