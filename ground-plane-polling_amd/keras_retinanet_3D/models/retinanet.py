@@ -97,6 +97,7 @@ class Plan(object):
         self.ops = []           # (kind, tag, desc, name, flops)
         self.oracle_names = {}  # fused ops: reference layer name of each output map (per-layer parity tests)
         self.lanes = []         # per op: side-stream lane << 8 | join flag (include/gpp.h GPP_OP_LANE / GPP_OP_JOIN)
+        self.op_batch = {}      # id(descriptor) -> images the launch covers where that is not the plan's batch (half-batch launches)
         self.array = None
         self.flops = 0.0
 
@@ -203,6 +204,7 @@ class RetinaNet3D(object):
     def _conv(self, plan, name, inputs, outputs, K, stride=1, pad=None, relu=False, residuals=None, out_f32=False, tag=0, lane=0,
               join=False, sync=False):
         d = self._desc(plan, name, inputs, outputs, K, stride, pad, relu, residuals, out_f32, lane)
+        plan.op_batch[id(d)] = inputs[0].B
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join, sync=sync)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
 
@@ -213,6 +215,7 @@ class RetinaNet3D(object):
         d2 = self._desc(plan, 'res{}_branch2c'.format(nm), [a], [y], 1, relu=True, residuals=[shortcut])
         plan.keep += [d1, d2]
         t = TailDesc(ctypes.addressof(d1), ctypes.addressof(d2), 0, 0)
+        plan.op_batch[id(t)] = a.B
         name = 'res{}_branch2b+2c'.format(nm)
         plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2), join=join, lane=lane)
         plan.io[name] = ([a], [y], [shortcut])
@@ -578,7 +581,7 @@ class RetinaNet3D(object):
                 self.run_op(plan, index)
                 continue
             if kind == OP_TAIL:
-                key = (name, B, H, Wd)
+                key = (name, plan.op_batch.get(id(desc), B), H, Wd)          # (a half-batch launch is tuned as what it is)
                 if key not in self._tuned:
                     times = {}
                     for rows in (96, 128, 160):
@@ -599,7 +602,7 @@ class RetinaNet3D(object):
                 continue
             if kind != OP_CONV:
                 continue
-            key = (name, B, H, Wd)
+            key = (name, plan.op_batch.get(id(desc), B), H, Wd)
             if key not in self._tuned:
                 iters = (2 if self.esz == 4 else 4) if flops > 5e10 else (4 if self.esz == 4 else 16)
                 hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(desc), iters, hip.stream_ptr(), ctypes.byref(best)),
