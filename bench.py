@@ -47,6 +47,9 @@ MEAN = np.array([103.939, 116.779, 123.68], np.float32)
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (f32: v_mfma_f32_16x16x4_f32 / 32x32x2, = the vector rate)
 # bf16x3: three bf16 matrix products per float32 product -> a third of the bf16 peak in float32-product FLOPs
 PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3.0, 'f16x3': 2500.0 / 3.0}
+# what the matrix pipe ALONE sustains on random operands (register-only MFMA loops, tools/micro/mfma_power.hip, profiles/r3/mfma_power.txt:
+# measured once, not by this script): the clock under matrix load depends on the data, zeros run at the nominal figure above
+PIPE_ON_RANDOM_DATA_TFLOPS = {'bf16': 2033.9, 'f16': 1753.4, 'bf16x3': 2033.9 / 3.0, 'f16x3': 1753.4 / 3.0}
 PROFILE_ROUND = 'r3'
 RESIDENT_BATCHES = 6      # the timed steps rotate over this many distinct resident batches (6 x 51 MB > the 256 MB Infinity Cache)
 
@@ -478,6 +481,12 @@ def main():
                          'launches_timed': len(durations), 'timed_on_steps': 'every {}rd of the {} timed steps'.format(EVENT_EVERY, args.steps),
                          'library': version},
         }
+        if args.dtype in PIPE_ON_RANDOM_DATA_TFLOPS:
+            rec['roofline']['pipe_on_random_data'] = round(PIPE_ON_RANDOM_DATA_TFLOPS[args.dtype], 1)
+            rec['roofline']['frac_of_pipe_on_random_data'] = round(achieved / PIPE_ON_RANDOM_DATA_TFLOPS[args.dtype], 4)
+            rec['roofline']['pipe_on_random_data_note'] = ('register-only MFMA loops on random operands, every CU busy (tools/micro/mfma_power.hip, '
+                                                          'profiles/r3/mfma_power.txt; measured once, not by this run): `peak` is the nominal dense figure, '
+                                                          'which the pipe reaches on all-zero operands only')
         if traffic_note:
             rec['roofline']['traffic_note'] = traffic_note
         if world == 1 and not args.no_cpu_baseline:
