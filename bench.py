@@ -50,6 +50,7 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3
 # what the matrix pipe ALONE sustains on random operands (register-only MFMA loops, tools/micro/mfma_power.hip, profiles/r3/mfma_power.txt:
 # measured once, not by this script): the clock under matrix load depends on the data, zeros run at the nominal figure above
 PIPE_ON_RANDOM_DATA_TFLOPS = {'bf16': 2033.9, 'f16': 1753.4, 'bf16x3': 2033.9 / 3.0, 'f16x3': 1753.4 / 3.0}
+PIPE_ON_POST_RELU_DATA_TFLOPS = {'bf16': 2134.7, 'f16': 1961.8, 'bf16x3': 2134.7 / 3.0, 'f16x3': 1961.8 / 3.0}      # half of the activation values zero
 PROFILE_ROUND = 'r3'
 RESIDENT_BATCHES = 6      # the timed steps rotate over this many distinct resident batches (6 x 51 MB > the 256 MB Infinity Cache)
 
@@ -484,6 +485,8 @@ def main():
         if args.dtype in PIPE_ON_RANDOM_DATA_TFLOPS:
             rec['roofline']['pipe_on_random_data'] = round(PIPE_ON_RANDOM_DATA_TFLOPS[args.dtype], 1)
             rec['roofline']['frac_of_pipe_on_random_data'] = round(achieved / PIPE_ON_RANDOM_DATA_TFLOPS[args.dtype], 4)
+            rec['roofline']['pipe_on_post_relu_data'] = round(PIPE_ON_POST_RELU_DATA_TFLOPS[args.dtype], 1)       # (what this layer reads)
+            rec['roofline']['frac_of_pipe_on_post_relu_data'] = round(achieved / PIPE_ON_POST_RELU_DATA_TFLOPS[args.dtype], 4)
             rec['roofline']['pipe_on_random_data_note'] = ('register-only MFMA loops on random operands, every CU busy (tools/micro/mfma_power.hip, '
                                                           'profiles/r3/mfma_power.txt; measured once, not by this run): `peak` is the nominal dense figure, '
                                                           'which the pipe reaches on all-zero operands only')

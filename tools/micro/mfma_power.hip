@@ -108,15 +108,16 @@ int main()
     uint4* d_ops; float* d_sink;
     CHECK(hipMalloc(&d_ops, 4096 * 16)); CHECK(hipMalloc(&d_sink, 64));
     srand(7);
-    for (int pass = 0; pass < 2; ++pass) {               // random data, then zeros
+    for (int pass = 0; pass < 3; ++pass) {               // random data, zeros, then max(random, 0) in the activation fragments (post-ReLU maps)
         for (int type = 0; type < 2; ++type) {
             for (size_t i = 0; i < h.size(); ++i) {
                 float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = (rand() + 1.0f) / (RAND_MAX + 2.0f);
-                float v = pass ? 0.0f : sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2) * 0.5f;
+                float v = pass == 1 ? 0.0f : sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2) * 0.5f;
+                if (pass == 2 && i < 8 * 64 * 8 && v < 0.0f) v = 0.0f;            // the first 8 x 64 x 8 values are the A (activation) fragments
                 h[i] = type ? f2bf(v) : f2h(v);
             }
             CHECK(hipMemcpy(d_ops, h.data(), 4096 * 16, hipMemcpyHostToDevice));
-            const char* data = pass ? "zeros" : "random";
+            const char* data = pass == 0 ? "random" : pass == 1 ? "zeros" : "relu(A)";
             if (type == 0) { run<0, false>("mfma 16x16x32 f16", d_ops, d_sink, data); run<1, false>("mfma 32x32x16 f16", d_ops, d_sink, data); }
             else { run<0, true>("mfma 16x16x32 bf16", d_ops, d_sink, data); run<1, true>("mfma 32x32x16 bf16", d_ops, d_sink, data); }
         }
