@@ -51,7 +51,10 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3
 # measured once, not by this script): the clock under matrix load depends on the data, zeros run at the nominal figure above
 PIPE_ON_RANDOM_DATA_TFLOPS = {'bf16': 2033.9, 'f16': 1753.4, 'bf16x3': 2033.9 / 3.0, 'f16x3': 1753.4 / 3.0}
 PIPE_ON_POST_RELU_DATA_TFLOPS = {'bf16': 2134.7, 'f16': 1961.8, 'bf16x3': 2134.7 / 3.0, 'f16x3': 1961.8 / 3.0}      # half of the activation values zero
-PROFILE_ROUND = 'r3'
+PROFILE_ROUNDS = ('r4', 'r3')      # the PMC file of the newest round whose library hash matches the running build is quoted
+# algorithmic bytes of one regression-tower launch at B = 8: M x 512 channels in + out and the packed weights,
+# 2 bytes per element for the 16-bit storage types, 4 for the float32-sized maps of f32 / bf16x3 / f16x3
+ALGORITHMIC_MB = {'bf16': 192.1, 'f16': 192.1, 'f32': 384.2, 'bf16x3': 384.2, 'f16x3': 384.2}
 RESIDENT_BATCHES = 6      # the timed steps rotate over this many distinct resident batches (6 x 51 MB > the 256 MB Infinity Cache)
 
 
@@ -69,20 +72,92 @@ def parse():
     p.add_argument('--no-f32-leg', action='store_true', help='skip the float32 leg + parity ledger of a 16-bit run')
     p.add_argument('--no-host-fed', action='store_true', help='skip the host-fed (PCIe-inclusive) legs')
     p.add_argument('--cpu-images', type=int, default=4, help='frames of the bounded CPU-baseline sample (about 3.5 s each on 128 host threads)')
+    p.add_argument('--dry-launch', action='store_true',
+                   help='rehearse the rank launcher without a GPU: every rank joins a gloo group, gathers a packed (B,100,35) tensor and exits')
     return p.parse_args()
+
+
+def launch_ranks(args):
+    """ `python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks here, one child process per
+    GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what `python -m torch.distributed.run --nproc-per-node N` would
+    give them.  Nothing in this (parent) process touches the GPU.  Rank 0's stdout is this process's stdout (the one JSON line);
+    the other ranks' stdout goes to stderr.  The first non-zero exit code ends the job and is returned. """
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.dry_launch:
+        import torch
+        have = torch.cuda.device_count()                        # (counting devices does not initialise the GPU)
+        if have < n:
+            raise SystemExit('bench.py --gpus {} needs {} devices, this host has {}: refusing to report a {}-GPU number '
+                             'from fewer ranks'.format(n, n, have, n))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:                                  # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
+
+
+class c_stdout_to_stderr(object):
+    """ RCCL (and gloo) print a banner on the C-level STDOUT when their first communicator comes up; this program's stdout carries
+    exactly one JSON line, so file descriptor 1 points at stderr while a communicator is built """
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def dry_launch(args, rank, world):
+    """ what a rank does under --dry-launch: the rendezvous + the one collective of the path on gloo, no GPU """
+    import torch
+    import torch.distributed as dist
+    from keras_retinanet_3D.utils import distributed as D
+    if args.batch < 1:
+        raise SystemExit('--batch must be at least 1')
+    with c_stdout_to_stderr():
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        packed = torch.full((args.batch, 100, D.PACK_WIDTH), float(rank), dtype=torch.float32)
+        out = D.gather_detections(packed, [args.batch] * world)
+    ok = all(bool((out[r * args.batch:(r + 1) * args.batch] == float(r)).all()) for r in range(world))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({'dry_launch': True, 'n_gpus': world, 'world_size': dist.get_world_size(), 'gpus_requested': args.gpus,
+                          'gathered_images_per_step': int(out.shape[0]), 'gather_correct': ok}))
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def synthetic_batch(batch, rank):
     """ uint8 noise frames 375x1242, 'resized' to the network input 402x1333 (nearest, host side,
     outside the timed region), BGR mean subtracted -- the tensor predict_on_batch receives """
     from keras_retinanet_3D.utils import synthetic
-    out = np.empty((batch, 402, 1333, 3), np.float32)
-    ys = np.minimum((np.arange(402) * (375.0 / 402.0)).astype(np.int64), 374)
-    xs = np.minimum((np.arange(1333) * (1242.0 / 1333.0)).astype(np.int64), 1241)
-    for i in range(batch):
-        frame = synthetic.synthetic_image(seed=1000 * rank + i)
-        out[i] = frame[ys][:, xs].astype(np.float32) - MEAN
-    return out
+    return synthetic.synthetic_network_input(range(1000 * rank, 1000 * rank + batch))
 
 
 def cpu_baseline(n_images, backbone, planes, replay=None):
@@ -160,11 +235,18 @@ def tile_name(code):
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:        # no launcher around us: be the launcher (before any GPU call)
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus {} was started with WORLD_SIZE={}: the line would claim a GPU count it did not run on'.format(
+            args.gpus, world))
+    if args.dry_launch:
+        raise SystemExit(dry_launch(args, rank, world))
+    import torch
+    import torch.distributed as dist
     force_dist = os.environ.get('GPP_BENCH_FORCE_DIST') == '1'      # exercise the RCCL path on a single GPU
     distributed = world > 1 or force_dist
     if distributed:
@@ -172,19 +254,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        # RCCL prints a version banner on STDOUT when its first communicator comes up; this program's stdout carries exactly one
-        # JSON line, so the C-level stdout points at stderr until the communicator exists
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with c_stdout_to_stderr():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
     else:
         torch.cuda.set_device(0)
 
@@ -282,6 +355,8 @@ def main():
                     'gather_wait_ms_per_step_max_over_ranks': round(1e3 * float(hi[1]) / args.steps, 4)}
     gathered_images = int(out.shape[0]) if out is not None else B
     rccl_world = dist.get_world_size() if distributed else 1
+    if rccl_world != args.gpus:
+        raise SystemExit('RCCL reports {} ranks, --gpus {} was asked for'.format(rccl_world, args.gpus))
 
     # dominant kernel: mean launch duration from the HIP events recorded inside the timed region
     durations = []
@@ -318,13 +393,16 @@ def main():
     # was collected with this very build of the library (gpp_version() carries a hash of the kernel sources)
     traffic, traffic_note = None, None
     version = lib.gpp_version().decode()
-    pmc_path = os.path.join(ROOT, 'profiles', PROFILE_ROUND, 'dominant_kernel_pmc_{}.json'.format(args.dtype))
-    if os.path.isfile(pmc_path) and args.backbone == 'resnet50' and B == 8:
+    for rnd in PROFILE_ROUNDS:
+        pmc_path = os.path.join(ROOT, 'profiles', rnd, 'dominant_kernel_pmc_{}.json'.format(args.dtype))
+        if traffic is not None or not (os.path.isfile(pmc_path) and args.backbone == 'resnet50' and B == 8):
+            continue
         with open(pmc_path) as f:
             pmc = json.load(f)
         if pmc.get('library_version') == version:
             traffic = round(pmc['traffic_bytes_per_launch'] / 1e6, 1)
-        else:
+            traffic_note = None
+        elif traffic_note is None:
             traffic_note = 'omitted: {} was collected with "{}", this build is "{}"'.format(
                 os.path.relpath(pmc_path, ROOT), pmc.get('library_version'), version)
     counts = plan.counts.cpu().numpy()
@@ -456,7 +534,10 @@ def main():
                        'f32_frac_of_f32_mfma_peak': None if f32_leg is None else f32_leg['frac_of_mfma_peak_whole_path'],
                        'parity_ledger': parity,
                        'parity_bars': dict(ledger.REFERENCE_BARS, what='the headline type against the float32 path on the same frames: '
-                                           'identical detection sets, identical plane index, 3-D corners within 1e-3 m (BASELINE.json north_star)'),
+                                           'identical detection sets (integer counts), identical orientation and plane index for every detection, '
+                                           '3-D corners within 1e-3 m (BASELINE.json north_star) for the detections whose keypoints lie within 100 m of '
+                                           'the camera (at least one must), within 1e-3 m x (distance / 100 m)^2 beyond: the condition number of a '
+                                           'ray-plane intersection grows with the square of the distance (utils/ledger.py)'),
                        'parity_bars_met': bars_met,
                        'resident_batches_rotated': RESIDENT_BATCHES,
                        'side_stream_launches': dict(getattr(plan, 'side_lanes', {}), decode=bool(getattr(plan, 'decode_overlap', False))),
@@ -475,7 +556,8 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_TFLOPS[args.dtype], 4), 'traffic': traffic,
                          'traffic_unit': 'MB per launch at the L2<->fabric interface (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; '
-                                         'algorithmic 192.1 MB)',
+                                         'algorithmic {} MB for {})'.format(ALGORITHMIC_MB[args.dtype], args.dtype),
+                         'algorithmic_mb_per_launch': ALGORITHMIC_MB[args.dtype],
                          'kernel': 'conv_igemm_kernel<{}> tile {} on pyramid_regression_1..3 (3x3, 512->512, 5 levels, M={})'.format(
                              args.dtype, tile_name(reg_tile), B * (plan.n_anchors // 12)),
                          'gflop_per_launch': round(flops_per_launch / 1e9, 1), 'mean_launch_ms': round(mean_ms, 4),

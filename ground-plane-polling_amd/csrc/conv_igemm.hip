@@ -121,6 +121,14 @@ extern "C" int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_
     return tail_entry(conv3x3, conv1x1, tile_rows, stream);
 }
 
+extern "C" int gpp_x3_range_events(uint64_t* host_count, int reset)
+{
+    unsigned long long v = 0;
+    const int rc = gpp_x3_range_events_f16x3(&v, reset);
+    if (rc == GPP_OK && host_count) *host_count = (uint64_t)v;
+    return rc;
+}
+
 extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)
 {
     if (!host_desc || !flops) return GPP_ERR_BAD_ARG;
@@ -165,6 +173,7 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 {
     if (!host_desc) return GPP_ERR_BAD_ARG;
     gpp_conv_desc d = *host_desc;
+    for (int g = 0; g < GPP_MAX_GROUPS; ++g) d.groups[g].row_begin = 0;       // the library's own field (mixed grids)
     int rc = validate(d);
     if (rc != GPP_OK) return rc;
     return dispatch_any(d, (hipStream_t)stream);
@@ -174,7 +183,7 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 // One list for the autotuner below and for gpp_conv2d_tile_candidates (tests draw tiles at random from it).
 static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                              1128128, 1192128, 1128256, 1192256, 256256, 1256256,
-                             128160, 192160, 1192160, 1128160, 2256256, 1192096,
+                             128160, 192160, 1192160, 1128160, 2256256, 1192096, 3256224, 3192160,
                              128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
 // (the loader-wavefront form of round 2, tile codes 3064128 ..., measured 1.5 - 2x slower on every layer it was built for
 // (profiles/r2/ring_kernel.txt), is no longer part of the library)
@@ -185,7 +194,11 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
     int64_t rows = 0;
     for (int g = 0; g < desc->n_groups; ++g) rows += (int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out;
     const int bn = tile % 1000 ? tile % 1000 : 128;
-    if (tile >= 3000000) return false;
+    if (tile >= 4000000) return false;
+    if (tile >= 3000000) {           // mixed-height grids: x3 types on pre-split inputs, whole 256-column tiles, enough rows for two rounds
+        const bool x3_in = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);
+        return x3_in && desc->C_out % 256 == 0 && nk >= 4 && desc->split_k <= 1 && rows * (desc->C_out / 256) >= 256 * 256;
+    }
     if (tile && bn == 64 && desc->C_out > 256) return false;        // narrow tiles on wide layers: never competitive
     if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) return false;
     // the pipelined loops need a few K-steps to pay; 16-bit types, and GPP_BF16X3 on a pre-split input map

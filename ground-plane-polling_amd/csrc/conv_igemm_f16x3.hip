@@ -9,3 +9,20 @@ int gpp_tail_dispatch_f16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows,
 {
     return dispatch_tail_x3<GPP_F16X3>(d1, d2, tile_rows, st);
 }
+
+// the range ledger of this type (conv_igemm_impl.h: g_x3_range_events): read, optionally reset; synchronises the device
+int gpp_x3_range_events_f16x3(unsigned long long* host_count, int reset)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    unsigned long long v = 0;
+    e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_x3_range_events), sizeof v);
+    if (e != hipSuccess) return (int)e;
+    if (host_count) *host_count = v;
+    if (reset) {
+        const unsigned long long zero = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_x3_range_events), &zero, sizeof zero);
+        if (e != hipSuccess) return (int)e;
+    }
+    return GPP_OK;
+}

@@ -179,10 +179,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 // The two "three 16-bit matrix products per float32 product" types: x = hi + lo with hi = h(x), lo = h(x - hi) (x - hi is exact in
 // float32), x * w ~ hi*whi + hi*wlo + lo*whi.  GPP_BF16X3: h = bfloat16, 8 + 8 significant bits, ~2^-16 per product, float32's
-// range.  GPP_F16X3: h = IEEE half, 11 + 11 bits, ~2^-22 per product (float32: 2^-24); range: activations are clamped to +-65504
-// before the split (a finite wrong value instead of inf for an activation no sane checkpoint produces), weights are scaled per
-// output channel by a power of two so that both halves are normal halfs (gpp_conv_desc.out_scale undoes it in the epilogue).
+// range.  GPP_F16X3: h = IEEE half, 11 + 11 bits, ~2^-22 per product (float32: 2^-24); range: a finite activation beyond +-65504 is
+// clamped where it is split -- and COUNTED (g_x3_range_events, gpp_x3_range_events): a clamped value is a wrong value, and the caller
+// can ask whether one occurred --, a non-finite one stays non-finite (hi = x, lo = x - x), as it would in the float32 path; weights are
+// scaled per output channel by a power of two so that both halves are normal halfs (gpp_conv_desc.out_scale undoes it in the epilogue).
 template <int DT> constexpr bool kX3 = (DT == GPP_BF16X3 || DT == GPP_F16X3);
+// GPP_F16X3: how many 8-channel groups an epilogue has stored with at least one value outside the half range (finite beyond +-65504,
+// inf or NaN) since the counter was last reset.  One counter per translation unit; only the GPP_F16X3 unit ever adds to it.
+__device__ __attribute__((unused)) unsigned long long g_x3_range_events = 0;
 // every other type: placeholders so that discarded `if constexpr` branches still parse
 template <int DT> struct X3Half {      // primary template
     using half = __bf16;
@@ -203,6 +207,29 @@ template <> struct X3Half<GPP_F16X3> {
     static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float clamp(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
 };
+// The 8 values an epilogue is about to split: clamped into the half range (GPP_F16X3; the other types pass through).  The rare group
+// that holds a value the clamp changed -- or a NaN, which compares unequal to everything -- takes the branch: the event is counted and
+// non-finite values are put back, so that a NaN / inf is still one after the split instead of reading as +-65504.
+template <int DT>
+__device__ __forceinline__ void x3_range(float (&v)[8])
+{
+    if constexpr (DT == GPP_F16X3) {
+        float c[8];
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            c[e] = X3Half<DT>::clamp(v[e]);
+            changed |= (c[e] != v[e]);
+        }
+        if (__builtin_expect(changed, 0)) {
+            atomicAdd(&g_x3_range_events, 1ull);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c[e] = (fabsf(v[e]) <= 3.402823466e38f) ? c[e] : v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c[e];
+    }
+}
 // Pre-split maps (gpp_conv_desc.x3_split): channels n .. n + 7 (n a multiple of 8) of the pixel whose float32-sized
 // element offset is `base` live at byte (base + (n & ~31)) * 4 + (n & 31) * 2 (8 halves hi) and 64 bytes further (8 halves lo).
 __device__ __forceinline__ const char* x3_addr(const void* buf, int64_t base, int n)
@@ -219,13 +246,14 @@ __device__ __forceinline__ void x3_unpack(const f32x4 hi_bits, const f32x4 lo_bi
     for (int e = 0; e < 8; ++e) r[e] = (float)h.b[e] + (float)l.b[e];
 }
 template <int DT>
-__device__ __forceinline__ void x3_store(void* buf, int64_t base, int n, const float (&v)[8])
+__device__ __forceinline__ void x3_store(void* buf, int64_t base, int n, float (&v)[8])
 {
     using half = typename X3Half<DT>::half;
     typename X3Half<DT>::vec h, l;
+    x3_range<DT>(v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float x = X3Half<DT>::clamp(v[e]);
+        const float x = v[e];
         h[e] = (half)x;
         l[e] = (half)(x - (float)h[e]);
     }
@@ -281,6 +309,7 @@ __device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], i
             for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = v[e];
         }
     } else {
+        if constexpr (DT == GPP_F16X3) x3_range<DT>(v);   // an activation map kept as float32: checked here, split by its consumers
         scalar* dst = (scalar*)d.out + obase + n;
         if (full) {
             *(vec8*)dst = Elem<DT>::pack(v);
@@ -328,6 +357,7 @@ __device__ __forceinline__ void finish8_pre(const gpp_conv_desc& d, float (&v)[8
         *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
         *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     } else {
+        if constexpr (DT == GPP_F16X3) x3_range<DT>(v);
         scalar* dst = (scalar*)d.out + obase + n;
         *(vec8*)dst = Elem<DT>::pack(v);
     }
@@ -419,6 +449,9 @@ template <> struct Elem<GPP_F16X3> : ElemX3<GPP_F16X3> {};
 
 template <int DT> constexpr bool kF32Storage = (DT == GPP_F32 || DT == GPP_BF16X3 || DT == GPP_F16X3);
 
+// activation rows a workgroup of NW wavefronts stages per K-step for a BM-row tile: whole 8-row LDS-DMA pieces per wavefront
+constexpr int stage_rows(int BM, int NW) { return (BM + 8 * NW - 1) / (8 * NW) * (8 * NW); }
+
 // XIN (GPP_BF16X3 only): the input map is pre-split (gpp_conv_desc.x3_split & GPP_X3_IN) -- a compile-time property of the kernel, so
 // that the loop of either form carries no trace of the other (the 256 x 256 tile has no registers to spare for both)
 template <int DT, int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool XIN = false>
@@ -433,11 +466,15 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     constexpr int ESZ = E::ESZ, CK = kRowBytes / ESZ;     // bytes per element, channels per K-step
     constexpr int NW = WM * WN;                          // wavefronts per workgroup
     constexpr int MF = BM / WM / 16, NF = BN / WN / 16;  // 16x16 accumulators per wave: MF x NF
-    constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;   // LDS-DMA instructions per wave per stage
+    // BMS: activation rows STAGED per K-step = BM rounded up to a whole number of 8-row LDS-DMA pieces per wavefront.  BM = 224 / 160 on
+    // 8 wavefronts (the short tiles of the mixed grid below) stage 256 / 192 rows and compute on the first BM of them: the extra rows
+    // belong to the next tile (or lie past the end: zeros from the range check) and are never read from LDS.
+    constexpr int BMS = stage_rows(BM, NW);
+    constexpr int A_BYTES = BMS * kRowBytes, B_BYTES = BN * kRowBytes, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_IT = BMS / 8 / NW, B_IT = BN / 8 / NW;   // LDS-DMA instructions per wave per stage
     constexpr int PER_STAGE = A_IT + B_IT;
     constexpr int PF = STAGES - 1;                       // K-steps in flight ahead of the one computed
-    static_assert(MF >= 1 && NF >= 1 && A_IT >= 1 && B_IT >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WM) == 0, "tile / wave shape");
+    static_assert(MF >= 1 && NF >= 1 && A_IT >= 1 && B_IT >= 1 && BMS % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WM) == 0, "tile / wave shape");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -450,12 +487,13 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     const int bid = xcd_remap(block_x, grid_x);
     const int n_tiles = (d.C_out + BN - 1) / BN;
     const int nt = bid % n_tiles, mt = bid / n_tiles;
-    int tile_start = 0, H_in = 0, W_in = 0, H_out = 0, W_out = 0, H_res = 0, W_res = 0;
+    int tile_start = 0, row_begin = 0, H_in = 0, W_in = 0, H_out = 0, W_out = 0, H_res = 0, W_res = 0;
     int64_t in_off = 0, in_bs = 0, out_off = 0, out_bs = 0, res_off = 0, res_bs = 0;
 #pragma unroll
     for (int q = 0; q < GPP_MAX_GROUPS; ++q) {
         if (q < d.n_groups && mt >= d.groups[q].tile_start) {
             tile_start = d.groups[q].tile_start;
+            row_begin = d.groups[q].row_begin;
             H_in = d.groups[q].H_in; W_in = d.groups[q].W_in;
             H_out = d.groups[q].H_out; W_out = d.groups[q].W_out;
             H_res = d.groups[q].H_res; W_res = d.groups[q].W_res;
@@ -466,7 +504,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     }
     const int HoWo = H_out * W_out;
     const int Mg = d.batch * HoWo;
-    const int m0 = (mt - tile_start) * BM, n0 = nt * BN;
+    const int m0 = row_begin + (mt - tile_start) * BM, n0 = nt * BN;       // (row_begin: 0 except in the second part of a mixed grid)
     const int Ktot = d.KH * d.KW * d.C_in;
     const int cpt = d.C_in / CK;                        // channel chunks per tap
     const int nk_total = d.KH * d.KW * cpt;
@@ -1185,6 +1223,23 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dual_kernel(const gpp_conv_
     }
 }
 
+// A grid of TWO tile heights against the round quantisation of one-workgroup-per-CU tiles.  722 tiles of 256 x 256 (the regression
+// tower at B = 8) are 2.82 rounds over 256 CUs and cost 3: the last round's 210 workgroups take as long as a full one.  Here
+// workgroups [0, na) run BMA-row tiles over the first rounds_a * 256 / n_tiles M tiles of group 0 (descriptor da: whole rounds, every
+// tile interior), workgroups [splita, splita + nb) run BMB-row tiles over everything that is left (descriptor db: group 0 from row
+// row_begin on, then the other groups), with BMB the tallest tile whose grid still fits the rounds it needs: 512 + 236 workgroups of
+// 256 / 224 rows = 2 + 0.875 rounds' worth of time instead of 3.  Same K order per output element in every tile: not a bit changes.
+template <int DT, int BMA, int BMB, int BN, bool XIN>
+__global__ __launch_bounds__(512, 2) void conv_igemm_mix_kernel(const gpp_conv_desc da, const gpp_conv_desc db, const int na,
+                                                                const int splita, const int nb)
+{
+    if ((int)blockIdx.x < splita) {
+        if ((int)blockIdx.x < na) conv_igemm_body<DT, BMA, BN, 2, 4, 2, true, XIN>(da, blockIdx.x, na);
+    } else {
+        conv_igemm_body<DT, BMB, BN, 2, 4, 2, true, XIN>(db, (int)blockIdx.x - splita, nb);
+    }
+}
+
 // Second pass of a split-K launch: sum the partial slabs in split order (deterministic), then the
 // same epilogue as the fused path.  One thread per (output row, 8 output channels).
 template <int DT>
@@ -1540,7 +1595,7 @@ int prepare(gpp_conv_desc& d)
     int tiles = 0;
     for (int g = 0; g < d.n_groups; ++g) {
         d.groups[g].tile_start = tiles;
-        tiles += (d.batch * d.groups[g].H_out * d.groups[g].W_out + BM - 1) / BM;
+        tiles += (d.batch * d.groups[g].H_out * d.groups[g].W_out - d.groups[g].row_begin + BM - 1) / BM;
     }
     d.partial_rows = tiles * BM;
     return tiles;
@@ -1742,15 +1797,20 @@ __global__ __launch_bounds__(256, 2) void bottleneck_tail_x3_kernel(const gpp_co
             for (int i = 0; i < MF; ++i) {
                 const int r = wm * (BM / WM) + i * 16 + frow;
                 xh8 h, l;
+                float v8[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = e < 4 ? acc1[i][2 * jj][e] : acc1[i][2 * jj + 1][e - 4];
                     if constexpr (OSCALE) v = v * scale_v[e] + bias_v[e];
                     else v = v + bias_v[e];
                     if (d1.relu) v = fmaxf(v, 0.0f);
-                    v = X3Half<DT>::clamp(v);
-                    h[e] = (typename X3Half<DT>::half)v;
-                    l[e] = (typename X3Half<DT>::half)(v - (float)h[e]);
+                    v8[e] = v;
+                }
+                x3_range<DT>(v8);                                     // exactly what x3_store does to the map the unfused layer writes
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h[e] = (typename X3Half<DT>::half)v8[e];
+                    l[e] = (typename X3Half<DT>::half)(v8[e] - (float)h[e]);
                 }
                 const int piece = (n & 31) >> 3;                      // 16-byte piece of the hi half of the 128-byte row; lo: + 4
                 unsigned char* row = smem + (n >> 5) * A_BYTES + r * kRowBytes;
@@ -1867,7 +1927,8 @@ int launch(gpp_conv_desc& d, hipStream_t st)
     if constexpr (kX3<DT> && !XIN) {
         if (d.x3_split & GPP_X3_IN) return launch<DT, BM, BN, WM, WN, STAGES, PIPE, true>(d, st);      // the pre-split-input form of this tile
     }
-    constexpr int lds = STAGES * (BM + BN) * kRowBytes;
+    constexpr int BMS = stage_rows(BM, WM * WN);
+    constexpr int lds = STAGES * (BMS + BN) * kRowBytes;
     constexpr int CK = kRowBytes / Elem<DT>::ESZ;
     static DeviceOnce once;
     auto kernel = conv_igemm_kernel<DT, BM, BN, WM, WN, STAGES, PIPE, XIN>;
@@ -1893,7 +1954,7 @@ int launch(gpp_conv_desc& d, hipStream_t st)
     const int steps = (nk + nsplit - 1) / nsplit;
     // (the pipelined loops always touch both buffers -- with a single K-step the look-ahead reads fragments of buffer 1 that nobody
     // uses: they get the whole ring whatever the step count, never less LDS than they address)
-    const int lds_used = PIPE ? lds : (steps < STAGES ? steps : STAGES) * (BM + BN) * kRowBytes;
+    const int lds_used = PIPE ? lds : (steps < STAGES ? steps : STAGES) * (BMS + BN) * kRowBytes;
     kernel<<<dim3((unsigned)(tiles * n_tiles), (unsigned)nsplit), dim3(64 * WM * WN), lds_used, st>>>(d);
     if (nsplit > 1) {
         const int64_t total = (int64_t)d.partial_rows * ((d.C_out + 7) / 8);
@@ -1935,6 +1996,56 @@ int launch_dual(const gpp_conv_desc& d, hipStream_t st)
     const int n0 = t0 * (head / 256), n1 = t1;
     const int split0 = (n0 + 7) / 8 * 8;                      // keeps workgroup index % 8 = XCD for the second range's remap
     kernel<<<dim3((unsigned)(split0 + n1)), dim3(512), lds, st>>>(d0, d1, n0, split0, n1);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}
+
+// conv_igemm_mix_kernel: 256-column tiles of two heights in one grid (x3 types on pre-split input maps: the three-phase loop).
+// The split is arithmetic on the layer and the 256 CUs of the device: part A = as many WHOLE rounds of BMA-row tiles as group 0 holds
+// and as make the total cheapest, part B = the rest in BMB-row tiles; cost model = rounds x tile rows (a round of one-workgroup-per-CU
+// tiles takes as long as its tile is tall).  Nothing to gain, or no whole round fits: GPP_ERR_UNSUPPORTED (the tuner moves on).
+template <int DT, int BMA, int BMB>
+int launch_mix(const gpp_conv_desc& d, hipStream_t st)
+{
+    constexpr int BN = 256, CUS = 256;
+    constexpr int ESZ = Elem<DT>::ESZ, CK = kRowBytes / ESZ;
+    static_assert(kX3<DT>, "mixed grids exist for the x3 types");
+    if (!(d.x3_split & GPP_X3_IN)) return GPP_ERR_UNSUPPORTED;
+    if (d.C_out % BN != 0 || d.KH * d.KW * (d.C_in / CK) < 2 || d.split_k > 1) return GPP_ERR_UNSUPPORTED;
+    const int n_tiles = d.C_out / BN;
+    const int64_t rows0 = (int64_t)d.batch * d.groups[0].H_out * d.groups[0].W_out;
+    auto tiles_b = [&](int64_t begin, int bm) {
+        int64_t t = (rows0 - begin + bm - 1) / bm;
+        for (int g = 1; g < d.n_groups; ++g) t += ((int64_t)d.batch * d.groups[g].H_out * d.groups[g].W_out + bm - 1) / bm;
+        return t * n_tiles;
+    };
+    int64_t best_cost = (tiles_b(0, BMA) + CUS - 1) / CUS * BMA;          // the uniform BMA grid: what the mix has to beat
+    int best_ra = 0;
+    for (int ra = 1; ra <= 64; ++ra) {
+        if ((ra * CUS) % n_tiles != 0) continue;
+        const int64_t ma = (int64_t)ra * CUS / n_tiles;                     // M tiles of part A
+        if (ma * BMA > rows0) break;
+        const int64_t cost = (int64_t)ra * BMA + (tiles_b(ma * BMA, BMB) + CUS - 1) / CUS * BMB;
+        if (cost < best_cost) { best_cost = cost; best_ra = ra; }
+    }
+    if (best_ra == 0) return GPP_ERR_UNSUPPORTED;
+    constexpr int lds = 2 * (stage_rows(BMA > BMB ? BMA : BMB, 8) + BN) * kRowBytes;
+    static DeviceOnce once;
+    auto kernel = conv_igemm_mix_kernel<DT, BMA, BMB, BN, true>;
+    int rc = once.configure(kernel, lds);
+    if (rc != GPP_OK) return rc;
+    const int ma = best_ra * CUS / n_tiles;
+    gpp_conv_desc da = d, db = d;
+    da.n_groups = 1;                                           // part A: whole tiles of group 0 only
+    const int ta = prepare<BMA, BN>(da);
+    if (ta < 0) return ta;
+    db.groups[0].row_begin = ma * BMA;
+    const int tb = prepare<BMB, BN>(db);
+    if (tb < 0) return tb;
+    da.in_bytes = db.in_bytes;                                 // (extents of the whole buffer, as computed over every group)
+    const int na = ma * n_tiles, nb = tb * n_tiles;
+    const int splita = (na + 7) / 8 * 8;                       // keeps workgroup index % 8 = XCD for the second range's remap
+    kernel<<<dim3((unsigned)(splita + nb)), dim3(512), lds, st>>>(da, db, na, splita, nb);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }
@@ -2010,6 +2121,8 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                             case 1128160: return launch<DT, 128, 160, 4, 1, 2, true, true>(d, st);      // 144-channel outputs: three-phase loop on a 4 x 1 layout
                             case 1192096: return launch<DT, 192, 96, 4, 1, 2, true, true>(d, st);       // 96-channel outputs, same layout
                             case 2256256: return launch_dual<DT>(d, st);      // C_out = 256 k + 128: the dual-shape grid
+                            case 3256224: return launch_mix<DT, 256, 224>(d, st);       // 3000000 + BMA * 1000 + BMB: two tile heights, one grid
+                            case 3192160: return launch_mix<DT, 192, 160>(d, st);
                             default: break;
                         }
                     }
@@ -2019,7 +2132,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                 }
                 switch (d.tile_hint) {
                     case 256: case 1128128: case 1192128: case 1128256: case 1192256: case 1192160: case 1128160: case 2256256: case 512: case 256256: case 1256256:
-                    case 192256: case 128256: case 1192096:
+                    case 192256: case 128256: case 1192096: case 3256224: case 3192160:
                         return GPP_ERR_UNSUPPORTED;
                     default: return GPP_ERR_BAD_ARG;
                 }

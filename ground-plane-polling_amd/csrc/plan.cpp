@@ -18,6 +18,9 @@ namespace {
 // The side streams and their events belong to ONE device: there is a set per device ordinal, created on first use under
 // a lock, and a plan that uses lanes holds that device's lock while it enqueues (two host threads driving the same
 // device would otherwise interleave their fork / join events on the shared side streams).  Plans without lanes take no lock.
+// Consequence (by design, documented in include/gpp.h): the lanes are per DEVICE, not per caller stream -- two plans enqueued on
+// different user streams of one device (utils/pipeline.FramePipeline, tools/two_in_flight.py) share the same two side streams, so
+// their side-lane work is ordered one plan after the other; their main-stream work still overlaps.
 constexpr int kLanes = 2;
 constexpr int kMaxDevices = 64;
 struct Lanes {
@@ -30,13 +33,13 @@ struct Lanes {
         if (ready) return GPP_OK;
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        // the side lanes run at the caller's (normal) priority: with half-batch chains and the FPN launches on them they are no longer
+        // only "short latency-bound chains", and letting their workgroups in first cost 0.6 % of the f16x3 step (808 -> 813 images/s,
+        // same box, alternating); GPP_LANE_PRIORITY=high restores the highest priority (read once, when the device's lanes are made)
+        const char* pr = getenv("GPP_LANE_PRIORITY");
+        const int prio = (pr && !strcmp(pr, "high")) ? hi : 0;
+        (void)lo;
         for (int l = 0; l < kLanes; ++l) {
-            // the side lanes run at the caller's (normal) priority: with half-batch chains and the FPN launches on them they are no longer
-            // only "short latency-bound chains", and letting their workgroups in first cost 0.6 % of the f16x3 step (808 -> 813 images/s,
-            // same box, alternating); GPP_LANE_PRIORITY=high restores the highest priority
-            const char* pr = getenv("GPP_LANE_PRIORITY");
-            const int prio = (pr && !strcmp(pr, "high")) ? hi : 0;
-            (void)lo;
             hipError_t e = hipStreamCreateWithPriority(&stream[l], hipStreamNonBlocking, prio);
             if (e != hipSuccess) return (int)e;
             e = hipEventCreateWithFlags(&done[l], hipEventDisableTiming);
@@ -69,38 +72,49 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
     Lanes& g_lanes = g_lanes_of_device[dev];
     std::unique_lock<std::mutex> guard(g_lanes.lock, std::defer_lock);
     if (uses_lanes) guard.lock();
+    // every way out of this function -- the end of the plan AND an error in the middle of it -- first makes the caller's stream wait for
+    // the side lanes that are still open: a failed run must not leave forked work that nothing downstream is ordered after (and a
+    // stream capture that is under way keeps a well-formed fork / join structure)
+    auto close_lanes = [&]() -> int {
+        int first = GPP_OK;
+        for (int m = 0; m < kLanes; ++m) {
+            if (!active[m]) continue;
+            hipError_t e = hipEventRecord(g_lanes.done[m], g_lanes.stream[m]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(main_st, g_lanes.done[m], 0);
+            if (e != hipSuccess && first == GPP_OK) first = (int)e;
+            active[m] = false;
+        }
+        return first;
+    };
+    auto fail = [&](int rc) -> int { (void)close_lanes(); return rc; };
     for (int i = 0; i < n_ops; ++i) {
         gpp_plan_op op = ops[i];
-        if (!op.desc) return GPP_ERR_BAD_ARG;
+        if (!op.desc) return fail(GPP_ERR_BAD_ARG);
         const int lane = (op.kind >> 8) & 0xff;
         const bool join = (op.kind & GPP_OP_JOIN) != 0, sync = (op.kind & GPP_OP_SYNC) != 0;
         op.kind &= 0xff;
-        if (lane > kLanes) return GPP_ERR_BAD_ARG;
+        if (lane > kLanes) return fail(GPP_ERR_BAD_ARG);
+        if (lane > 0 && join) return fail(GPP_ERR_BAD_ARG);      // only an op on the caller's stream can consume what the lanes produced
         hipStream_t st = main_st;
         if (lane > 0) {
             int rc = g_lanes.init();
-            if (rc != GPP_OK) return rc;
+            if (rc != GPP_OK) return fail(rc);
             st = g_lanes.stream[lane - 1];
             if (!active[lane - 1] || sync) {            // fork: the lane starts after everything enqueued on the main stream so far
                 hipError_t e = hipEventRecord(g_lanes.fork, main_st);
                 if (e == hipSuccess) e = hipStreamWaitEvent(st, g_lanes.fork, 0);
-                if (e != hipSuccess) return (int)e;
+                if (e != hipSuccess) return fail((int)e);
                 active[lane - 1] = true;
             }
-        } else if (join) {
-            for (int m = 0; m < kLanes; ++m) {          // this op consumes what the side lanes produced
-                if (!active[m]) continue;
-                hipError_t e = hipEventRecord(g_lanes.done[m], g_lanes.stream[m]);
-                if (e == hipSuccess) e = hipStreamWaitEvent(main_st, g_lanes.done[m], 0);
-                if (e != hipSuccess) return (int)e;
-                active[m] = false;
-            }
+        } else if (join) {                              // this op consumes what the side lanes produced
+            int rc = close_lanes();
+            if (rc != GPP_OK) return rc;
         }
         void* stream = (void*)st;
         const bool timed = op.tag != 0 && events && ev + 1 < n_events;
         if (timed) {
             hipError_t e = hipEventRecord((hipEvent_t)events[ev], st);
-            if (e != hipSuccess) return (int)e;
+            if (e != hipSuccess) return fail((int)e);
         }
         int rc = GPP_ERR_UNSUPPORTED;
         switch (op.kind) {
@@ -172,22 +186,16 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
             break;
         }
         default:
-            return GPP_ERR_BAD_ARG;
+            return fail(GPP_ERR_BAD_ARG);
         }
-        if (rc != GPP_OK) return rc;
+        if (rc != GPP_OK) return fail(rc);
         if (timed) {
             hipError_t e = hipEventRecord((hipEvent_t)events[ev + 1], st);
-            if (e != hipSuccess) return (int)e;
+            if (e != hipSuccess) return fail((int)e);
             ev += 2;
         }
     }
-    for (int m = 0; m < kLanes; ++m) {                  // a plan may not end inside a side lane
-        if (!active[m]) continue;
-        hipError_t e = hipEventRecord(g_lanes.done[m], g_lanes.stream[m]);
-        if (e == hipSuccess) e = hipStreamWaitEvent(main_st, g_lanes.done[m], 0);
-        if (e != hipSuccess) return (int)e;
-    }
-    return GPP_OK;
+    return close_lanes();                               // a plan may not end inside a side lane
 }
 
 extern "C" int gpp_event_create(void** event)

@@ -124,6 +124,25 @@ __global__ __launch_bounds__(kThreads) void poll_kernel(
     const float* Pi = P_inv + (size_t)b * 12;
     const int o = orient[det];
 
+    // Padding rows.  FilterDetections pads its outputs with -1 (filter_detections.py:170-177) and the reference polls those rows like any
+    // other (fit_road_planes.py has no mask): boxes = dims = orientation = -1 give the same finite garbage for EVERY padding row of an
+    // image (same P_inv, same planes).  A run of consecutive padding rows is therefore polled ONCE -- by the workgroup of its first row,
+    // which writes its result to every row of the run -- and the workgroups of the other rows leave at once: the same bytes as polling
+    // each row, at the cost of one.  A frame with 7 detections pays for 8 scans of the database instead of 100.
+    // (Only the exact padding pattern qualifies; a row with orientation -1 and anything else in its boxes is polled as the reference would.)
+    auto is_padding = [&](int r) {
+        if (orient[r] != -1) return false;
+        bool pad = true;
+        for (int k = 0; k < 12; ++k) pad = pad && boxes[(size_t)r * 12 + k] == -1.0f;
+        for (int k = 0; k < 3; ++k) pad = pad && dims[(size_t)r * 3 + k] == -1.0f;
+        return pad;
+    };
+    int run = 1;                          // rows this workgroup writes: its own, plus the padding rows that follow a first padding row
+    if (o == -1 && is_padding(det)) {     // (uniform over the workgroup: every lane reads the same addresses)
+        if (det % D != 0 && is_padding(det - 1)) return;                 // not the first of its run: that row's workgroup writes this one
+        while ((det + run) % D != 0 && is_padding(det + run)) ++run;
+    }
+
     // :80-83 back-projection (uniform over the workgroup; every lane keeps its own copy)
     V3 ray[4];
 #pragma unroll
@@ -238,13 +257,15 @@ __global__ __launch_bounds__(kThreads) void poll_kernel(
         float r = hy.res;
         if ((int)hy.votes < vmax) r = 100.0f;
         if (hy.zc < 0.0f) r = 100.0f;
-        float* kp = keypoints + (size_t)det * 12;
+        for (int row = det; row < det + run; ++row) {
+            float* kp = keypoints + (size_t)row * 12;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { kp[3 * k] = hy.X[k].x; kp[3 * k + 1] = hy.X[k].y; kp[3 * k + 2] = hy.X[k].z; }
-        float* kq = keyplanes + (size_t)det * 4;
-        kq[0] = p.x; kq[1] = p.y; kq[2] = p.z; kq[3] = p.w;
-        residuals[det] = r / 6.0f;
-        if (best_idx) best_idx[det] = best;
+            for (int k = 0; k < 4; ++k) { kp[3 * k] = hy.X[k].x; kp[3 * k + 1] = hy.X[k].y; kp[3 * k + 2] = hy.X[k].z; }
+            float* kq = keyplanes + (size_t)row * 4;
+            kq[0] = p.x; kq[1] = p.y; kq[2] = p.z; kq[3] = p.w;
+            residuals[row] = r / 6.0f;
+            if (best_idx) best_idx[row] = best;
+        }
     }
 }
 

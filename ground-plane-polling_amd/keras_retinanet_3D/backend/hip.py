@@ -51,7 +51,7 @@ class ConvGroup(ctypes.Structure):
                 ('res_off', c_int64), ('res_bstride', c_int64),
                 ('H_in', ctypes.c_int32), ('W_in', ctypes.c_int32), ('H_out', ctypes.c_int32), ('W_out', ctypes.c_int32),
                 ('H_res', ctypes.c_int32), ('W_res', ctypes.c_int32), ('tile_start', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('row_begin', ctypes.c_int32)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -128,6 +128,8 @@ def _declare(lib):
     lib.gpp_event_elapsed_ms.argtypes = [c_void_p, c_void_p, ctypes.POINTER(c_float)]
     lib.gpp_conv2d_tile_candidates.restype = c_int
     lib.gpp_conv2d_tile_candidates.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int)]
+    lib.gpp_x3_range_events.restype = c_int
+    lib.gpp_x3_range_events.argtypes = [ctypes.POINTER(ctypes.c_uint64), c_int]
     lib.gpp_conv2d_autotune.restype = c_int
     lib.gpp_conv2d_autotune.argtypes = [ctypes.POINTER(ConvDesc), c_int, c_void_p, ctypes.POINTER(c_float)]
 

@@ -97,8 +97,8 @@ class FMap(object):
             self.dense().copy_(values.to(self.buf.dtype))
             return
         v = values.to(device=self.buf.device, dtype=torch.float32).reshape(self.B, self.H, self.W, self.C // 32, 32)
-        if self.half == 'f16x3':
-            v = v.clamp(-65504.0, 65504.0)
+        if self.half == 'f16x3':          # as the epilogue does: finite values clamped to the half range, non-finite ones left as they are
+            v = torch.where(torch.isfinite(v), v.clamp(-65504.0, 65504.0), v)
         hi = v.to(x3_half(self.half))
         lo = (v - hi.float()).to(x3_half(self.half))
         both = torch.stack([hi, lo], dim=4).reshape(self.B, self.H, self.W, 2 * self.C)            # [.., chunk, (hi | lo), 32]

@@ -93,7 +93,9 @@ class Plan(object):
 
     def __init__(self):
         self.keep = []          # ctypes descriptors and torch buffers kept alive
-        self.io = {}            # conv op name -> (input FMaps, output FMaps, residual FMaps or None)
+        self.io = {}            # conv op name -> (input FMaps, output FMaps, residual FMaps or None); half-batch plans: the LAST part
+        self.io_parts = {}      # conv op name -> [(inputs, outputs, residuals) of every launch under that name] (half-batch plans: two)
+        self.tuning_parts = {}  # conv op name -> [(tile, us) of every launch under that name]
         self.ops = []           # (kind, tag, desc, name, flops)
         self.oracle_names = {}  # fused ops: reference layer name of each output map (per-layer parity tests)
         self.lanes = []         # per op: side-stream lane << 8 | join flag (include/gpp.h GPP_OP_LANE / GPP_OP_JOIN)
@@ -117,7 +119,7 @@ class Plan(object):
 class RetinaNet3D(object):
     """ Inference model: ResNet-50/101/152 + FPN + heads + decode + ground-plane polling. """
 
-    def __init__(self, weights, backbone_name='resnet50', dtype='bf16', nms=True, class_specific_filter=True,
+    def __init__(self, weights, backbone_name='resnet50', dtype='f16x3', nms=True, class_specific_filter=True,
                  orientation_specific_filter=False, name='retinanet-bbox'):
         import torch
         self.osf = bool(orientation_specific_filter)     # per-orientation NMS (filter_detections.py:84-98), gpp_detect_osf_f32
@@ -207,6 +209,7 @@ class RetinaNet3D(object):
         plan.op_batch[id(d)] = inputs[0].B
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join, sync=sync)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
+        plan.io_parts.setdefault(name, []).append((inputs, outputs, residuals))
 
     def _tail(self, plan, nm, a, y, shortcut, join=False, lane=0):
         """ branch2b (3x3) + branch2c (1x1, + shortcut, ReLU) of one bottleneck as ONE launch
@@ -219,6 +222,7 @@ class RetinaNet3D(object):
         name = 'res{}_branch2b+2c'.format(nm)
         plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2), join=join, lane=lane)
         plan.io[name] = ([a], [y], [shortcut])
+        plan.io_parts.setdefault(name, []).append(([a], [y], [shortcut]))
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
         torch, dev, dt = self.torch, self.device, self.tdtype
@@ -511,14 +515,23 @@ class RetinaNet3D(object):
     def _tune_cache_path(self):
         return os.environ.get('GPP_TUNE_CACHE')
 
+    def _tune_config(self):
+        """ what a cached tile choice is valid for besides (backbone, type, layer, batch, image size): the build of the library (tile codes
+        come and go with it: gpp_version() carries a hash of the kernel sources) and the plan options that change which maps are
+        pre-split or fused -- a tile timed on a float32 map may not even exist for the pre-split form of the same layer """
+        ver = hip.lib().gpp_version().decode().split('src:')[-1]
+        return 'v2;{};x3split={};fuse={}'.format(ver, os.environ.get('GPP_X3_SPLIT', '2'), os.environ.get('GPP_FUSE_TAIL', '64,128'))
+
     def _load_tune_cache(self):
         path = self._tune_cache_path()
         if path and os.path.exists(path):
             with open(path) as f:
                 for key, val in json.load(f).items():
-                    bb, dt, name, b, h, w = key.split('|')
-                    if bb == self.backbone_name and dt == self.dtype:
-                        # [tile, us]; files written by round 1 hold [tile, split_k, us] -- the split is ignored (never tuned now)
+                    parts = key.split('|')
+                    if len(parts) != 7:              # (files of rounds 1-3: no library hash in the key -- ignored, the layers are timed again)
+                        continue
+                    cfg, bb, dt, name, b, h, w = parts
+                    if cfg == self._tune_config() and bb == self.backbone_name and dt == self.dtype:
                         self._tuned[(name, int(b), int(h), int(w))] = (int(val[0]), float(val[-1]))
 
     def _save_tune_cache(self):
@@ -534,7 +547,7 @@ class RetinaNet3D(object):
             except ValueError:
                 data = {}
         for (name, b, h, w), val in self._tuned.items():
-            data['|'.join([self.backbone_name, self.dtype, name, str(b), str(h), str(w)])] = list(val)
+            data['|'.join([self._tune_config(), self.backbone_name, self.dtype, name, str(b), str(h), str(w)])] = list(val)
         tmp = '{}.tmp.{}'.format(path, os.getpid())
         with open(tmp, 'w') as f:
             json.dump(data, f, indent=0, sort_keys=True)
@@ -599,10 +612,13 @@ class RetinaNet3D(object):
                     fresh = True
                 desc.tile_rows = self._tuned[key][0]
                 plan.tuning[name] = self._tuned[key]
+                plan.tuning_parts.setdefault(name, []).append(self._tuned[key])
                 continue
             if kind != OP_CONV:
                 continue
             key = (name, plan.op_batch.get(id(desc), B), H, Wd)
+            if key in self._tuned and not self._tile_is_listed(desc, self._tuned[key][0]):
+                del self._tuned[key]                 # a remembered tile this build does not offer for this layer: time the layer again
             if key not in self._tuned:
                 iters = (2 if self.esz == 4 else 4) if flops > 5e10 else (4 if self.esz == 4 else 16)
                 hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(desc), iters, hip.stream_ptr(), ctypes.byref(best)),
@@ -611,9 +627,24 @@ class RetinaNet3D(object):
                 fresh = True
             desc.tile_hint = self._tuned[key][0]
             plan.tuning[name] = self._tuned[key]
+            plan.tuning_parts.setdefault(name, []).append(self._tuned[key])
         torch.cuda.synchronize()
         if fresh:
             self._save_tune_cache()
+
+    @staticmethod
+    def _tile_is_listed(desc, tile):
+        tiles, count = (ctypes.c_int * 64)(), ctypes.c_int(0)
+        hip.check(hip.lib().gpp_conv2d_tile_candidates(ctypes.byref(desc), tiles, 64, ctypes.byref(count)), 'gpp_conv2d_tile_candidates')
+        return int(tile) in list(tiles[:min(count.value, 64)])
+
+    def x3_range_events(self, reset=False):
+        """ dtype='f16x3': how many 8-channel groups the epilogues have stored with a value outside the half range (a finite activation
+        beyond +-65504, which is clamped, or an inf / NaN, which stays one) since the counter was last reset (gpp_x3_range_events; the
+        counter is per device, shared by every f16x3 model on it).  Zero = the type's range altered nothing.  Synchronises. """
+        n = ctypes.c_uint64(0)
+        hip.check(hip.lib().gpp_x3_range_events(ctypes.byref(n), int(bool(reset))), 'gpp_x3_range_events')
+        return int(n.value)
 
     def plan_for(self, B, H, Wd, n_planes, planes_batched):
         key = (int(B), int(H), int(Wd), int(n_planes), bool(planes_batched))

@@ -29,13 +29,25 @@ RANGE_M = 100.0
 # BASELINE.json north_star: "bit-exact plane-index/argmax selection, 3D box corners within 1e-3" against the reference-precision
 # path on identical inputs.  A throughput mode may be quoted as the BASELINE metric only when its ledger against the float32 path
 # meets all three (bench.py enforces it for its headline type, tests/test_fullsize_gpu.py for 'f16x3').
-REFERENCE_BARS = {'detection_set_agreement': 1.0, 'plane_index_agreement': 1.0, 'max_corner_dev_m_within_100m': 1e-3}
+#
+# Beyond 100 m (round 4): a keypoint is the intersection of a pixel ray with a road plane, z = d f / (v - c_y), so a pixel
+# perturbation dv moves it by dz = z^2 / (d f) dv -- the condition number grows with the SQUARE of the distance (camera height
+# d ~ 1.65 m, focal length f ~ 774 px at the network's scale: 7.8 m per pixel at 100 m, i.e. 1e-3 m there is 1.3e-4 px, four
+# float32 ulps of a pixel coordinate).  The bar for a detection whose farthest coordinate is r > 100 m is therefore
+# 1e-3 m x (r / 100 m)^2: continuous at 100 m, the same bound on the pixel-space perturbation at every distance
+# ('max_corner_dev_scaled_beyond_100m' = max over those detections of deviation / (r / 100)^2).
+REFERENCE_BARS = {'detection_set_agreement': 1.0, 'plane_index_agreement': 1.0, 'max_corner_dev_m_within_100m': 1e-3,
+                  'max_corner_dev_scaled_beyond_100m': 1e-3}
 
 
 def meets_reference_bars(led):
-    """ the same detections, the same plane for every one of them, 3-D corners within 1e-3 m """
-    return bool(led['detection_set_agreement'] == 1.0 and led['plane_index_agreement'] == 1.0 and
-                led['orientation_agreement'] == 1.0 and led['max_corner_dev_m_within_100m'] <= 1e-3)
+    """ the same detections, the same orientation and plane for every one of them (integer counts, not rounded ratios), 3-D corners
+    within 1e-3 m wherever the geometry lies within 100 m -- and at least one detection must lie there, an empty set meets nothing --,
+    within 1e-3 m x (r / 100 m)^2 beyond """
+    return bool(led['common'] == led['union'] and led['same_orientation'] == led['common'] and led['same_plane'] == led['common'] and
+                led['common'] > 0 and led['same_plane_within_100m'] > 0 and
+                led['max_corner_dev_m_within_100m'] <= REFERENCE_BARS['max_corner_dev_m_within_100m'] and
+                led['max_corner_dev_scaled_beyond_100m'] <= REFERENCE_BARS['max_corner_dev_scaled_beyond_100m'])
 
 
 def _dev(a, b):
@@ -58,15 +70,18 @@ def _per_image(outs, anchor_index, plane_index, b):
     return det
 
 
-def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane):
+def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane, detail=None):
     """ ref_* : the 8 output arrays + (B, 100) anchor ids + (B, 100) selected plane indices of the reference-precision
-    run; outs / anchor / plane: the same of the run under test.  Returns a dict of plain numbers. """
+    run; outs / anchor / plane: the same of the run under test.  Returns a dict of plain numbers.
+    detail: a list that receives one (image, anchor id, reach_m, corner_dev_m, keypoint_dev_m, same_plane) tuple per common detection
+    (tools/corner_deviation.py draws the distribution from it). """
     B = int(np.asarray(ref_outs[0]).shape[0])
     n_ref = n_got = n_common = 0
     same_orient = same_plane = 0
     max_kp = max_corner = max_box = max_score = 0.0
     max_kp_rel = max_corner_rel = 0.0
-    in_range = 0
+    max_corner_far = 0.0
+    in_range = beyond = 0
     identical_images = 0
     for b in range(B):
         A = _per_image(ref_outs, ref_anchor, ref_plane, b)
@@ -102,20 +117,29 @@ def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane):
         if near.any():
             max_kp = max(max_kp, float(kp[near].max()))
             max_corner = max(max_corner, float(cd[near].max()))
+        far = sp & ~(reach <= RANGE_M)
+        beyond += int(far.sum())
+        if far.any():
+            with np.errstate(all='ignore'):
+                scaled = np.where(np.isfinite(reach[far]), cd[far] / (reach[far] / RANGE_M) ** 2, np.where(cd[far] == 0.0, 0.0, np.inf))
+            max_corner_far = max(max_corner_far, float(scaled.max()))
+        if detail is not None:
+            detail.extend((b, int(a), float(r_), float(c_), float(k_), bool(s_)) for a, r_, c_, k_, s_ in zip(common, reach, cd, kp, sp))
         if sp.any():
             scale = np.maximum(np.where(np.isfinite(reach), reach, 1.0), 1.0)
             max_kp_rel = max(max_kp_rel, float((kp[sp] / scale[sp]).max()))
             max_corner_rel = max(max_corner_rel, float((cd[sp] / scale[sp]).max()))
     union = n_ref + n_got - n_common
     return {
-        'images': B, 'detections_ref': n_ref, 'detections': n_got, 'common': n_common,
+        'images': B, 'detections_ref': n_ref, 'detections': n_got, 'common': n_common, 'union': union,
+        'same_orientation': same_orient, 'same_plane': same_plane,
         'detection_set_agreement': round(n_common / union, 6) if union else 1.0,          # Jaccard index over anchor ids
         'detection_recall_of_ref': round(n_common / n_ref, 6) if n_ref else 1.0,
         'images_with_identical_detection_lists': identical_images,
         'orientation_agreement': round(same_orient / n_common, 6) if n_common else 1.0,
         'plane_index_agreement': round(same_plane / n_common, 6) if n_common else 1.0,
         'max_score_diff': max_score, 'max_box_diff_px': max_box,
-        'same_plane_within_100m': in_range,
+        'same_plane_within_100m': in_range, 'same_plane_beyond_100m': beyond, 'max_corner_dev_scaled_beyond_100m': max_corner_far,
         'max_keypoint_dev_m_within_100m': max_kp, 'max_corner_dev_m_within_100m': max_corner,
         'max_keypoint_rel_dev': max_kp_rel, 'max_corner_rel_dev': max_corner_rel,
     }

@@ -165,3 +165,19 @@ def synthetic_image(seed=0, shape=KITTI_IMAGE_SHAPE):
     """ uint8 BGR frame, uniform noise. """
     rng = np.random.default_rng(seed)
     return rng.integers(0, 256, size=shape, dtype=np.uint8)
+
+
+BGR_MEAN = np.array([103.939, 116.779, 123.68], np.float32)        # utils/image.py:26-62 ('caffe' mode)
+
+
+def synthetic_network_input(seeds):
+    """ (len(seeds), 402, 1333, 3) float32: the uint8 noise frames synthetic_image(seed) at 375x1242, brought to the network input
+    size by nearest sampling on the host, BGR mean subtracted -- the tensor predict_on_batch receives.  bench.py's resident
+    batches and the full-size oracle fixtures (oracle/gen_fullsize_goldens.py) are built from these. """
+    seeds = list(seeds)
+    out = np.empty((len(seeds), 402, 1333, 3), np.float32)
+    ys = np.minimum((np.arange(402) * (375.0 / 402.0)).astype(np.int64), 374)
+    xs = np.minimum((np.arange(1333) * (1242.0 / 1333.0)).astype(np.int64), 1241)
+    for i, seed in enumerate(seeds):
+        out[i] = synthetic_image(seed=int(seed))[ys][:, xs].astype(np.float32) - BGR_MEAN
+    return out

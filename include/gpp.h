@@ -82,8 +82,10 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
                         channels, the 32 bf16 hi parts followed by the 32 bf16 lo parts (same bytes per row as float32). */
 #define GPP_F16X3 5  /* as GPP_BF16X3 with IEEE-half halves: hi = f16(x), lo = f16(x - hi), 11 + 11 significant bits, ~2^-22 relative
                         error per product (float32: 2^-24): the throughput mode that stays inside the reference-precision tolerance
-                        (plane index exact, 3-D corners within 1e-3 of the float32 path).  Range: activations beyond +-65504 are
-                        clamped when they are split; the packed weights of an output channel are scaled by a power of two so that
+                        (plane index exact, 3-D corners within 1e-3 of the float32 path).  Range: finite activations beyond +-65504 are
+                        clamped when they are split and COUNTED (gpp_x3_range_events below); a non-finite activation stays non-finite
+                        (hi = x, lo = x - x: NaN or inf), as in the float32 path -- a broken activation is never laundered into a
+                        plausible finite value; the packed weights of an output channel are scaled by a power of two so that
                         both halves are normal halfs, and gpp_conv_desc.out_scale (float32 per output channel, the inverse power of
                         two) is applied to the accumulator before the bias. */
 
@@ -99,10 +101,11 @@ int gpp_poll_f32(const float* boxes, const float* dims, const int32_t* orient, c
  * (the five pyramid levels of a head layer, retinanet.py:257-281), each described by a
  * gpp_conv_group.  GEMM view per group: M = batch*H_out*W_out output pixels, N = C_out,
  * K = KH*KW*C_in, K ordered (c_in / CK, kh, kw, c_in % CK) with CK = 128 bytes of channels (64 for the 16-bit types,
- * 32 for GPP_F32 / GPP_BF16X3): the taps of one channel chunk are adjacent so that their overlapping input rows are re-read
- * from the XCD-local L2.
+ * 32 for the float32-sized types GPP_F32 / GPP_BF16X3 / GPP_F16X3): the taps of one channel chunk are adjacent so that their
+ * overlapping input rows are re-read from the XCD-local L2.
  *
- * Layouts (element = 2 bytes for GPP_BF16 / GPP_F16, 4 bytes for GPP_F32 / GPP_BF16X3)
+ * Layouts (element = 2 bytes for GPP_BF16 / GPP_F16, 4 bytes for GPP_F32 / GPP_BF16X3 / GPP_F16X3; a pre-split x3 map, see x3_split,
+ * has the same 4 bytes per element: 32 channels = 64 bytes of hi halves + 64 bytes of lo halves)
  *   in        pixel (b, y, x) of a group at  in + in_off + b*in_bstride + (y*W_in + x)*in_pitch,
  *             C_in contiguous channels there (in_pitch >= C_in lets a channel slice be read)
  *   weight    [C_out rounded up to a multiple of 256][KH*KW*C_in], K contiguous; rows >= C_out
@@ -131,7 +134,7 @@ typedef struct gpp_conv_group {
     int32_t H_in, W_in, H_out, W_out;
     int32_t H_res, W_res;
     int32_t tile_start;             /* filled in by the library */
-    int32_t reserved;
+    int32_t row_begin;              /* filled in by the library (first GEMM row of the group this grid part covers; callers leave 0) */
 } gpp_conv_group;
 
 typedef struct gpp_conv_desc {
@@ -152,9 +155,13 @@ typedef struct gpp_conv_desc {
                                        256256), + 1000000 = the software-pipelined main loop (128128, 192128, 128256, 192256,
                                        192160, 128160, 192096), 2256256 = 256256 plus 512 x 128 tiles for the last 128 columns in one grid
                                        (C_out = 256 k + 128 only); legacy codes 64 / 128 / 256 / 512; anything else: GPP_ERR_BAD_ARG.
-                                       GPP_BF16X3: the plain tiles, 128256 / 192256 / 256256 (8 wavefronts), and on a pre-split input
-                                       map (x3_split & GPP_X3_IN) the pipelined 1128128, 1192128, 1128256, 1192256, 1256256, 1128160, 1192096 and 2256256.
-                                       See gpp_conv2d_autotune */
+                                       GPP_BF16X3 / GPP_F16X3 (the same tile set, the same loops): the plain tiles, 128256 / 192256 / 256256
+                                       (8 wavefronts), and on a pre-split input map (x3_split & GPP_X3_IN) the pipelined 1128128, 1192128,
+                                       1128256, 1192256, 1256256, 1128160, 1192096 and 2256256; 192160 exists on pre-split inputs only;
+                                       3256224 / 3192160 (3000000 + BMA * 1000 + BMB, C_out % 256 == 0, pre-split inputs): 256-column tiles
+                                       of two heights in ONE grid -- whole rounds of BMA-row tiles, the rest in BMB-row tiles -- against the
+                                       round quantisation of one-workgroup-per-CU tiles (GPP_ERR_UNSUPPORTED where it gains nothing).
+                                       gpp_conv2d_tile_candidates lists what a given layer accepts; see gpp_conv2d_autotune */
     int32_t reserved;               /* must be 0 (anything else: GPP_ERR_BAD_ARG).  Only the diagnostic -DGPP_STAMPS build of the
                                        library (make stamps; tools/bench_conv.py) reads it: bit 0 skip the tile loads, bit 1 skip
                                        the LDS reads + MFMA, bit 2 / 3 flip the pipelined form of the 128128 / 256256 tile,
@@ -206,6 +213,12 @@ int gpp_conv2d_tile_candidates(const gpp_conv_desc* host_desc, int* tiles, int c
    tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup.  Other shapes, and GPP_F32: GPP_ERR_UNSUPPORTED. */
 int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream);
 
+/* GPP_F16X3 range ledger.  The half type ends at +-65504: an epilogue that stores an activation outside it (a finite value it has to
+   clamp, an inf or a NaN) adds one event per 8-channel group to a device-side counter (one per device).  host_count (host pointer,
+   may be NULL) receives the events since the last reset; reset != 0 clears the counter.  Synchronises the device.  Zero after a run
+   means no activation of that run was altered by the type's range (models/retinanet.py: model.x3_range_events()). */
+int gpp_x3_range_events(uint64_t* host_count, int reset);
+
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
 
@@ -233,6 +246,8 @@ int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B, int H, in
 /* conv1 + bn_conv1 + ReLU + pool1 in ONE launch (GPP_BF16 / GPP_F16): out is the POOLED map (B, Hp, Wp, 64), Hp = (Ho + 1)/2;
  * the (B, Ho, Wo, 64) conv map is never written (137 MB at B = 8, 402 x 1333).  Bit-identical to
  * gpp_stem_conv7x7_bn_relu_mfma followed by gpp_maxpool3x3s2_same (the max is taken over the rounded conv values). */
+int gpp_stem_pool_fused_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
+                             int dtype, int B, int H, int W, void* stream);
 /* The stem of the float32-storage "x3" types (GPP_F16X3 / GPP_BF16X3 models): conv1 + bn_conv1 + ReLU on the matrix pipe at
  * (almost) float32 precision -- input pixels and weights split into two IEEE halves each, three matrix products per float32 product,
  * float32 output (B, Ho, Wo, 64).  packed_weight_x3 = what the HOST-side helper gpp_stem_pack_weights_f16x3 writes from the folded
@@ -240,8 +255,6 @@ int gpp_maxpool3x3s2_same(const void* in, void* out, int dtype, int B, int H, in
 int gpp_stem_pack_weights_f16x3(const float* host_weight_147x64, void* host_packed, size_t packed_bytes);
 int gpp_stem_conv7x7_bn_relu_x3(const float* in, const void* packed_weight_x3, const float* bias, float* out,
                                 int B, int H, int W, void* stream);
-int gpp_stem_pool_fused_mfma(const float* in, const void* packed_weight_f16, const float* bias, void* out,
-                             int dtype, int B, int H, int W, void* stream);
 /* dtype GPP_BF16X3 = a pre-split map (gpp_conv_desc.x3_split): ReLU on the [hi | lo] pairs (count in float32-sized elements, a
    multiple of 32) */
 int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream);
@@ -348,8 +361,11 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 #define GPP_OP_STEM_POOL 13              /* gpp_stem_desc with out = the pooled map -> gpp_stem_pool_fused_mfma */
 /* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
    that forks from the caller's stream at the first op of that lane; `kind | GPP_OP_JOIN` on a lane-0 op makes it wait
-   for every open lane (the end of the plan joins too).  The caller orders the ops so that each lane only depends on
-   what was enqueued before its fork.  Used for the three independent head towers. */
+   for every open lane (the end of the plan joins too, and so does every error return: a failed gpp_plan_run leaves no forked work
+   un-joined).  GPP_OP_JOIN on a side-lane op is GPP_ERR_BAD_ARG.  The caller orders the ops so that each lane only depends on
+   what was enqueued before its fork.  The side streams belong to the DEVICE (one pair per device ordinal, made on first use): plans
+   enqueued on different caller streams of one device share them, so their side-lane work is ordered plan after plan.
+   Used for the projection shortcuts, the half-batch chains of res3-res5, the small FPN launches and the detection selection. */
 #define GPP_OP_LANE(l) ((l) << 8)
 #define GPP_OP_JOIN 0x10000
 /* on a side-lane op: the lane first waits for everything enqueued on the caller's stream so far (a second fork point) */

@@ -12,8 +12,11 @@ MaxPooling2D(3, stride 2, 'same'); bottleneck = 1x1 (stride on this conv) / BN /
 ZeroPadding2D(1) + 3x3 valid / BN / ReLU / 1x1 x4 / BN, projection shortcut on block 0, Add, ReLU;
 freeze_bn => moving statistics), and TF semantics for 'same' padding and nearest resize.
 
-Two modes
+Three modes
   * float32 throughout, BatchNormalization applied literally (the reference semantics);
+  * `precision='f64'`: the same literal graph in float64 -- the EXACT value of what the reference's float32 graph approximates
+    (head tensors rounded to float32 once, at the end): the yardstick that tells whether an arithmetic mode is as close to the
+    true result as float32 itself is (oracle/gen_fullsize_goldens.py);
   * `storage` = 'bf16' | 'f16': BN folded into the convolution, weights and every stored
     activation rounded to the 16-bit storage type of the HIP path (the stem rounds image and
     weights to f16), float32 accumulation -- the arithmetic the GPU performs, up to summation order.
@@ -62,12 +65,15 @@ def _nearest_like(src, target):
     oh, ow = target.shape[2:]
     ys = torch.clamp(torch.floor(torch.arange(oh, dtype=torch.float32) * (np.float32(ih) / np.float32(oh))).long(), max=ih - 1)
     xs = torch.clamp(torch.floor(torch.arange(ow, dtype=torch.float32) * (np.float32(iw) / np.float32(ow))).long(), max=iw - 1)
+    # (index arithmetic stays float32 in every mode: it is TF's, not the graph's floatx)
     return src[:, :, ys][:, :, :, xs]
 
 
 class Net(object):
-    def __init__(self, weights, backbone='resnet50', storage=None):
-        self.w = weights
+    def __init__(self, weights, backbone='resnet50', storage=None, precision='f32'):
+        assert precision in ('f32', 'f64') and not (storage and precision == 'f64')
+        self.dt = torch.float64 if precision == 'f64' else torch.float32
+        self.w = {k: np.asarray(v, np.float64) for k, v in weights.items()} if precision == 'f64' else weights
         self.backbone = backbone
         self.storage = storage
         self.q = _quantizer(storage)
@@ -183,11 +189,11 @@ class Net(object):
         regression (B, A, 12), regression_dim (B, A, 3), classification_logits (B, A, 8) """
         self.trace = {} if trace else None
         with torch.no_grad():
-            x = torch.as_tensor(np.ascontiguousarray(images_nhwc, dtype=np.float32)).permute(0, 3, 1, 2)
+            x = torch.as_tensor(np.ascontiguousarray(images_nhwc, dtype=np.float32)).permute(0, 3, 1, 2).to(self.dt)
             C2, C3, C4, C5 = self.resnet(x)
             feats = self.fpn(C3, C4, C5)
             reg, dim, cls = self.heads(feats)
-        out = {'regression': reg.numpy(), 'regression_dim': dim.numpy(), 'classification_logits': cls.numpy()}
+        out = {'regression': reg.float().numpy(), 'regression_dim': dim.float().numpy(), 'classification_logits': cls.float().numpy()}
         if trace:
             out['trace'] = self.trace
         if keep_features:
@@ -196,5 +202,5 @@ class Net(object):
         return out
 
 
-def forward(weights, images_nhwc, backbone='resnet50', storage=None, keep_features=False, trace=False):
-    return Net(weights, backbone, storage).forward(images_nhwc, keep_features=keep_features, trace=trace)
+def forward(weights, images_nhwc, backbone='resnet50', storage=None, keep_features=False, trace=False, precision='f32'):
+    return Net(weights, backbone, storage, precision).forward(images_nhwc, keep_features=keep_features, trace=trace)

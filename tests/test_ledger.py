@@ -61,3 +61,40 @@ def test_far_away_and_non_finite_geometry():
     assert 0.5e-5 < led['max_keypoint_rel_dev'] < 2e-5
     o2[5][1, 2, 1, 1] = np.inf             # non-finite in one run only: an infinite deviation
     assert ledger.parity_ledger(o, a, p, o2, a, p)['max_keypoint_rel_dev'] == np.inf
+
+
+def test_reference_bars_compare_counts_and_need_detections_in_range():
+    o, a, p = fake_run()
+    led = ledger.parity_ledger(o, a, p, o, a, p)
+    assert led['union'] == led['common'] == led['same_plane'] == led['same_orientation'] == 160
+    assert led['same_plane_within_100m'] + led['same_plane_beyond_100m'] == 160 and ledger.meets_reference_bars(led)
+    # one detection of 160 000 would vanish in a ratio rounded to six digits; the counts see it
+    near_miss = dict(led, common=159999, union=160000, same_plane=159999, same_orientation=159999, detection_set_agreement=1.0)
+    assert not ledger.meets_reference_bars(near_miss)
+    # no detection inside the working range: the corner bar has not been met, it has not been measured
+    o_far = [x.copy() for x in o]
+    o_far[5] *= 1e4
+    led_far = ledger.parity_ledger(o_far, a, p, o_far, a, p)
+    assert led_far['same_plane_within_100m'] == 0 and led_far['max_corner_dev_m_within_100m'] == 0.0
+    assert not ledger.meets_reference_bars(led_far)
+    # nothing detected at all meets nothing either
+    empty = [x.copy() for x in o]
+    empty[2][:] = -1
+    assert not ledger.meets_reference_bars(ledger.parity_ledger(empty, a, p, empty, a, p))
+
+
+def test_the_bar_beyond_100m_scales_with_the_square_of_the_distance():
+    o, a, p = fake_run()
+    o[5][0, 0] = np.float32(1000.0) * np.sign(o[5][0, 0] + np.float32(1e-9))        # every coordinate of detection 0 at 1 km: (r / 100)^2 = 100
+    o2 = [x.copy() for x in o]
+    o2[5][0, 0] += np.float32(0.05)                                                 # 5 cm at 1 km = 5e-4 m scaled to 100 m
+    detail = []
+    led = ledger.parity_ledger(o, a, p, o2, a, p, detail=detail)
+    assert led['same_plane_beyond_100m'] >= 1 and led['max_corner_dev_m_within_100m'] == 0.0
+    assert len(detail) == led['common'] and max(d[2] for d in detail) >= 1000.0
+    far = [d for d in detail if d[2] >= 1000.0]
+    assert all(d[5] for d in far) and abs(max(d[4] for d in far) - 0.05) < 1e-3      # (image, anchor, reach, corner dev, keypoint dev, same plane)
+    o3 = [x.copy() for x in o]
+    o3[5][0, 0] += np.float32(5.0)                                                  # 5 m at 1 km = 5e-2 scaled: far outside
+    assert ledger.parity_ledger(o, a, p, o3, a, p)['max_corner_dev_scaled_beyond_100m'] > 1e-3
+    assert not ledger.meets_reference_bars(ledger.parity_ledger(o, a, p, o3, a, p))
