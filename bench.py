@@ -442,22 +442,40 @@ def main():
         torch.cuda.empty_cache()
         return res, state
 
+    # ---- the run under test against the CPU ORACLE, from the committed full-size fixtures (tests/golden/fullsize_*.npz, made by
+    # oracle/gen_fullsize_goldens.py: the oracle's detections for frames 0 .. of every BASELINE backbone / plane database; batch 0 of
+    # rank 0 is frames 0 .. B-1).  f64 = the conv stack in float64: the exact value of what the reference's float32 graph computes --
+    # THE bars (utils/ledger.REFERENCE_BARS) are measured against it; f32 = one float32 CPU evaluation, informational
+    oracle_ledgers = {}
+    fixture = os.path.join(ROOT, 'tests', 'golden', 'fullsize_{}_{}_{{}}.npz'.format(args.backbone, args.planes))
+    if rank == 0 and world == 1 and os.path.isfile(fixture.format('f64')):
+        for prec in ('f64', 'f32'):
+            g = np.load(fixture.format(prec))
+            if len(g['frames']) >= B:
+                ref = ([g[k][:B] for k in ('boxes', 'dimensions', 'scores', 'labels', 'orientations', 'keypoints', 'keyplanes', 'residuals')],
+                       g['anchor_index'][:B], g['plane_index'][:B])
+                led = ledger.parity_ledger(*(ref + (main_outs, main_anchor, main_plane)))
+                led['what'] = '{} HIP path vs the {} CPU oracle (committed fixture), frames 0..{}'.format(args.dtype, prec, B - 1)
+                led['meets_reference_bars'] = ledger.meets_reference_bars(led, pair=(prec == 'f32'))
+                oracle_ledgers[prec] = led
+
     f32_leg = None
     parity = None
     other_legs = {}
-    bars_met = None
+    bars_met = oracle_ledgers['f64']['meets_reference_bars'] if 'f64' in oracle_ledgers else None
     if extras and args.dtype != 'f32' and not args.no_f32_leg:
         f32_leg, ref_state = leg('f32', 10)
         parity = ledger.parity_ledger(*(ref_state + (main_outs, main_anchor, main_plane)))
-        parity['what'] = '{} HIP path vs float32 HIP path, same {} frames, same weights'.format(args.dtype, B)
-        bars_met = ledger.meets_reference_bars(parity)
+        parity['what'] = '{} HIP path vs float32 HIP path, same {} frames, same weights (two float32-grade runs: pair bars, 2e-3 m)'.format(args.dtype, B)
+        parity['meets_reference_bars_as_a_pair'] = ledger.meets_reference_bars(parity, pair=True)
+        bars_met = parity['meets_reference_bars_as_a_pair'] and (bars_met is None or bars_met)
         if args.all_dtypes:
             for other in ('bf16x3', 'f16', 'bf16', 'f16x3'):
                 if other == args.dtype:
                     continue
                 res, state = leg(other, 8)
                 res['parity_ledger_vs_f32'] = ledger.parity_ledger(*(ref_state + state))
-                res['meets_reference_bars'] = ledger.meets_reference_bars(res['parity_ledger_vs_f32'])
+                res['meets_reference_bars'] = ledger.meets_reference_bars(res['parity_ledger_vs_f32'], pair=True)
                 other_legs[other] = res
 
     # informational, outside the timed region and never `value`: the same step fed from HOST memory --
@@ -533,11 +551,16 @@ def main():
                        'f32_achieved_tflops_whole_path': None if f32_leg is None else f32_leg['achieved_tflops_whole_path'],
                        'f32_frac_of_f32_mfma_peak': None if f32_leg is None else f32_leg['frac_of_mfma_peak_whole_path'],
                        'parity_ledger': parity,
-                       'parity_bars': dict(ledger.REFERENCE_BARS, what='the headline type against the float32 path on the same frames: '
-                                           'identical detection sets (integer counts), identical orientation and plane index for every detection, '
-                                           '3-D corners within 1e-3 m (BASELINE.json north_star) for the detections whose keypoints lie within 100 m of '
-                                           'the camera (at least one must), within 1e-3 m x (distance / 100 m)^2 beyond: the condition number of a '
-                                           'ray-plane intersection grows with the square of the distance (utils/ledger.py)'),
+                       'parity_ledger_vs_f64_oracle': oracle_ledgers.get('f64'),
+                       'parity_ledger_vs_f32_cpu_oracle': oracle_ledgers.get('f32'),
+                       'parity_bars': dict(ledger.REFERENCE_BARS, what='the type under test against the float64 CPU oracle of the same frames (the exact '
+                                           'value of what the reference graph computes; committed fixture): identical detection sets up to ties at the '
+                                           'top-k cut (integer counts), identical orientation and plane index for every detection, 3-D corners within '
+                                           '1e-3 m (BASELINE.json north_star) for the detections whose keypoints lie within 100 m of the camera (at least '
+                                           'one must), within 1e-3 m x (distance / 100 m)^2 beyond (the condition number of a ray-plane intersection '
+                                           'grows with the square of the distance); AND against the float32 HIP path of the same run at twice the metre '
+                                           'bars (two float32-grade evaluations: the float32 CPU oracle itself is 1.15e-3 m from the float64 one, '
+                                           'utils/ledger.py)'),
                        'parity_bars_met': bars_met,
                        'resident_batches_rotated': RESIDENT_BATCHES,
                        'side_stream_launches': dict(getattr(plan, 'side_lanes', {}), decode=bool(getattr(plan, 'decode_overlap', False))),

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "conv_igemm_types.h"
 #include "gpp.h"
@@ -195,6 +196,8 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
     for (int g = 0; g < desc->n_groups; ++g) rows += (int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out;
     const int bn = tile % 1000 ? tile % 1000 : 128;
     if (tile >= 4000000) return false;
+    static const bool no_mix = [] { const char* e = getenv("GPP_NO_MIX_TILES"); return e && e[0] == '1'; }();      // (A/B of the mixed grids)
+    if (tile >= 3000000 && no_mix) return false;
     if (tile >= 3000000) {           // mixed-height grids: x3 types on pre-split inputs, whole 256-column tiles, enough rows for two rounds
         const bool x3_in = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);
         return x3_in && desc->C_out % 256 == 0 && nk >= 4 && desc->split_k <= 1 && rows * (desc->C_out / 256) >= 256 * 256;

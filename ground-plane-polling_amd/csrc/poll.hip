@@ -138,9 +138,18 @@ __global__ __launch_bounds__(kThreads) void poll_kernel(
         return pad;
     };
     int run = 1;                          // rows this workgroup writes: its own, plus the padding rows that follow a first padding row
+    __shared__ int s_run;
     if (o == -1 && is_padding(det)) {     // (uniform over the workgroup: every lane reads the same addresses)
         if (det % D != 0 && is_padding(det - 1)) return;                 // not the first of its run: that row's workgroup writes this one
-        while ((det + run) % D != 0 && is_padding(det + run)) ++run;
+        // length of the run: the lanes look at the following rows of the image in parallel (a serial walk over 93 rows of 15 dependent
+        // loads each cost more than the scan it saves)
+        const int left = D - 1 - det % D;                                // rows of this image behind this one
+        if (tid == 0) s_run = left + 1;
+        __syncthreads();
+        for (int r = 1 + tid; r <= left; r += kThreads)
+            if (!is_padding(det + r)) atomicMin(&s_run, r);
+        __syncthreads();
+        run = s_run;
     }
 
     // :80-83 back-projection (uniform over the workgroup; every lane keeps its own copy)

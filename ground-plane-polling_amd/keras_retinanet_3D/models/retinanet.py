@@ -313,7 +313,7 @@ class RetinaNet3D(object):
             # two independent chains in flight overlap one's prologue / epilogue / barrier waits with the other's main loop (f16x3 step,
             # same box, alternating: 775 -> 793 images/s).  An image's result does not depend on its batch (section 4.4): same bytes.
             # The halves stay apart until the FPN's first layer joins them; the per-block shortcut stream is not used inside them.
-            halves = stage in half_stages and B >= 2 and not env_chunks
+            halves = stage in half_stages and B >= 2 and chunk >= B       # (a stage that is chunked runs its chunks one after the other)
             # (three parts on three streams, measured: 801 against 811 images/s for two)
             parts = [(B // 2, B - B // 2, 1), (0, B // 2, 0)] if halves else [(c0, min(chunk, B - c0), 0) for c0 in range(0, B, chunk)]
             xs_of = {c0: sub(xin, c0, nb) for c0, nb, _ in parts}

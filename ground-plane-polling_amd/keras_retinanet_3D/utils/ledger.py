@@ -38,16 +38,33 @@ RANGE_M = 100.0
 # ('max_corner_dev_scaled_beyond_100m' = max over those detections of deviation / (r / 100)^2).
 REFERENCE_BARS = {'detection_set_agreement': 1.0, 'plane_index_agreement': 1.0, 'max_corner_dev_m_within_100m': 1e-3,
                   'max_corner_dev_scaled_beyond_100m': 1e-3}
+#
+# What the bars are measured AGAINST (round 4, profiles/r4/corner_deviation_*.txt: 64 frames, 6400 detections).  The reference's graph is
+# float32; the exact value of what it computes is the float64 evaluation of the same graph (oracle/net_torch.py precision='f64',
+# tests/golden/fullsize_*_f64.npz).  Float32 itself is not within 1e-3 m of that everywhere: the float32 CPU oracle's largest corner
+# deviation from the float64 oracle over 5901 detections within 100 m is 1.15e-3 m (p99 2.1e-4), and two float32 evaluations with
+# different summation orders (float32 HIP vs float32 CPU) differ by up to 1.25e-3 m.  So
+#   * REFERENCE_BARS are for a run against the EXACT (float64) oracle -- f16x3 HIP: 6.1e-4 m, closer than either float32 evaluation;
+#   * a comparison of two float32-grade runs (pair=True: HIP f32 vs CPU f32, f16x3 vs HIP f32) is held to twice the metre bars: both
+#     being within 1e-3 of the exact value puts them within 2e-3 of each other, no closer.
+# Detection sets.  A detection is in the top-100 or not by its score; two evaluations of a score differ by up to ~5e-7 (measured
+# 4.2e-7), so when the 100th and 101st candidates of a frame are closer than that, WHICH of them is reported is decided by rounding
+# noise -- in the float32 reference as much as here (resnet152 / 22k planes, frame 0: the two candidates are 2.6e-8 apart in float64,
+# and the float32 CPU oracle reports the other one than the float64 oracle does).  A set difference counts as explained by a TIE AT
+# THE CUT when both lists are full and the unmatched detection's score is within TIE_EPS of the other run's lowest reported score;
+# every other difference is unexplained and fails the bars.
+TIE_EPS = 1e-6
 
 
-def meets_reference_bars(led):
-    """ the same detections, the same orientation and plane for every one of them (integer counts, not rounded ratios), 3-D corners
-    within 1e-3 m wherever the geometry lies within 100 m -- and at least one detection must lie there, an empty set meets nothing --,
-    within 1e-3 m x (r / 100 m)^2 beyond """
-    return bool(led['common'] == led['union'] and led['same_orientation'] == led['common'] and led['same_plane'] == led['common'] and
+def meets_reference_bars(led, pair=False):
+    """ the same detections (up to ties at the top-k cut), the same orientation and plane for every common one (integer counts, not
+    rounded ratios), 3-D corners within 1e-3 m wherever the geometry lies within 100 m -- and at least one detection must lie there, an
+    empty set meets nothing --, within 1e-3 m x (r / 100 m)^2 beyond.  pair: two float32-grade runs against each other (2e-3). """
+    f = 2.0 if pair else 1.0
+    return bool(led['set_differences_unexplained'] == 0 and led['same_orientation'] == led['common'] and led['same_plane'] == led['common'] and
                 led['common'] > 0 and led['same_plane_within_100m'] > 0 and
-                led['max_corner_dev_m_within_100m'] <= REFERENCE_BARS['max_corner_dev_m_within_100m'] and
-                led['max_corner_dev_scaled_beyond_100m'] <= REFERENCE_BARS['max_corner_dev_scaled_beyond_100m'])
+                led['max_corner_dev_m_within_100m'] <= f * REFERENCE_BARS['max_corner_dev_m_within_100m'] and
+                led['max_corner_dev_scaled_beyond_100m'] <= f * REFERENCE_BARS['max_corner_dev_scaled_beyond_100m'])
 
 
 def _dev(a, b):
@@ -76,7 +93,7 @@ def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane, detail=N
     detail: a list that receives one (image, anchor id, reach_m, corner_dev_m, keypoint_dev_m, same_plane) tuple per common detection
     (tools/corner_deviation.py draws the distribution from it). """
     B = int(np.asarray(ref_outs[0]).shape[0])
-    n_ref = n_got = n_common = 0
+    n_ref = n_got = n_common = ties = 0
     same_orient = same_plane = 0
     max_kp = max_corner = max_box = max_score = 0.0
     max_kp_rel = max_corner_rel = 0.0
@@ -92,6 +109,14 @@ def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane, detail=N
         n_ref += len(pos_a)
         n_got += len(pos_g)
         n_common += len(common)
+        only_a, only_g = sorted(set(pos_a) - set(pos_g)), sorted(set(pos_g) - set(pos_a))
+        if only_a or only_g:
+            full = len(pos_a) == len(pos_g) == int(np.asarray(ref_outs[2]).shape[1])          # both lists hold max_detections entries
+            cut_a, cut_g = float(A['scores'].min()) if len(pos_a) else 0.0, float(G['scores'].min()) if len(pos_g) else 0.0
+            for a in only_a:
+                ties += int(full and abs(float(A['scores'][pos_a[a]]) - cut_g) <= TIE_EPS)
+            for a in only_g:
+                ties += int(full and abs(float(G['scores'][pos_g[a]]) - cut_a) <= TIE_EPS)
         identical_images += int(list(A['anchor']) == list(G['anchor']))
         if not common:
             continue
@@ -133,6 +158,8 @@ def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane, detail=N
     return {
         'images': B, 'detections_ref': n_ref, 'detections': n_got, 'common': n_common, 'union': union,
         'same_orientation': same_orient, 'same_plane': same_plane,
+        'set_differences': n_ref + n_got - 2 * n_common, 'set_differences_at_a_tie': ties,
+        'set_differences_unexplained': n_ref + n_got - 2 * n_common - ties,
         'detection_set_agreement': round(n_common / union, 6) if union else 1.0,          # Jaccard index over anchor ids
         'detection_recall_of_ref': round(n_common / n_ref, 6) if n_ref else 1.0,
         'images_with_identical_detection_lists': identical_images,

@@ -36,9 +36,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # the reference-precision leg and the ledger of the headline type against it, measured by the same run: the headline has to
     # meet BASELINE.json's tolerance (same detections, same planes, corners within 1e-3 m) and its throughput target (>= 500)
     assert cfg['f32_images_per_s'] > 20 and 0.2 < cfg['f32_frac_of_f32_mfma_peak'] < 1.0
-    led = cfg['parity_ledger']
+    led = cfg['parity_ledger']                              # f16x3 HIP vs f32 HIP: two float32-grade runs, twice the metre bars
     assert led['images'] == 8 and led['detections_ref'] > 400
-    assert led['detection_set_agreement'] == 1.0 and led['plane_index_agreement'] == 1.0 and led['max_corner_dev_m_within_100m'] <= 1e-3
+    assert led['set_differences_unexplained'] == 0 and led['plane_index_agreement'] == 1.0 and led['max_corner_dev_m_within_100m'] <= 2e-3
+    assert led['meets_reference_bars_as_a_pair'] is True
+    exact = cfg['parity_ledger_vs_f64_oracle']              # against the float64 CPU oracle (committed fixture): THE bars
+    assert exact['images'] == 8 and exact['common'] == exact['union'] == 800 and exact['same_plane'] == 800
+    assert exact['max_corner_dev_m_within_100m'] <= 1e-3 and exact['max_corner_dev_scaled_beyond_100m'] <= 1e-3 and exact['meets_reference_bars'] is True
+    assert cfg['parity_ledger_vs_f32_cpu_oracle']['meets_reference_bars'] is True
     assert cfg['parity_bars_met'] is True and rec['value'] >= 500.0
     others = cfg['other_types_same_frames']               # --all-dtypes: the faster types, none of which meets the bars with these weights
     assert others['bf16']['images_per_s'] > 1000 and others['bf16']['meets_reference_bars'] is False
@@ -78,3 +83,16 @@ def test_bench_stdout_is_one_json_line_on_the_rccl_path():
     diag = rec['config']['multi_gpu_diagnosis']               # what a scaling run is read with: per-rank step time, exposed gather time
     assert 0 < diag['ms_per_step_min_over_ranks'] <= diag['ms_per_step_max_over_ranks'] <= rec['ms_per_step'] * 1.05
     assert 0 <= diag['gather_wait_ms_per_step_max_over_ranks'] < rec['ms_per_step']
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """ `bench.py --gpus 2` on a one-GPU box: the launcher counts the devices before it starts a rank and fails loudly -- it never
+    reports a 2-GPU line from one rank (tests/test_bench_launcher.py rehearses the launcher itself on gloo) """
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('this box has the devices')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and 'needs 2 devices' in out.stderr and out.stdout.strip() == ''

@@ -386,3 +386,90 @@ def test_x3_bottleneck_tail_needs_pre_split_maps_and_64_channels():
     d1, d2, keep3 = layer_pair(64, True)
     assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 64, hip.stream_ptr()) == -1
     assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 0, hip.stream_ptr()) == 0
+
+
+def _pyramid_layer(cin, cout, shapes, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device('cuda')
+    total = sum(h * w for h, w in shapes)
+    xbuf = torch.empty((B, total, cin), dtype=torch.float32, device=dev)
+    k = torch.randn((3, 3, cin, cout), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    w = C.pack_weight(k.numpy(), 'f16x3', dev)
+    scale = C.out_scale_of(k.numpy(), dev)
+    b = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    ins, off = [], 0
+    for h, wd in shapes:
+        fm = C.FMap(xbuf, B, h, wd, cin, off=off * cin, bstride=total * cin, split=True, half='f16x3')
+        fm.write(torch.randn((B, h, wd, cin), generator=g))
+        ins.append(fm)
+        off += h * wd
+
+    def run(tile):
+        o = torch.full((B, total, cout), float('nan'), dtype=torch.float32, device=dev)
+        outs, off = [], 0
+        for h, wd in shapes:
+            outs.append(C.FMap(o, B, h, wd, cout, off=off * cout, bstride=total * cout, split=True, half='f16x3'))
+            off += h * wd
+        d = C.conv_desc(ins, outs, w, b, 3, 3, cin, cout, pad=(1, 1), relu=True, dtype='f16x3', tile_hint=tile, out_scale=scale)
+        rc = hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr())
+        return rc, o, d
+    return run
+
+
+@pytest.mark.parametrize('cout,tile', [(256, 3256224), (256, 3192160), (512, 3256224), (512, 3192160)])
+def test_mixed_height_grid_gives_the_bits_of_the_plain_tile(cout, tile):
+    """ tile codes 3256224 / 3192160: whole rounds of 256- (192-) row tiles over the head of the first map, 224- (160-) row tiles over
+    the rest of it and over the other maps, ONE grid (the short tiles stage 256 / 192 rows and compute on 224 / 160).  The first map is
+    large enough for a whole round of 256 workgroups; the others are ragged.  Bits of the plain 128 x 128 tile and of 1256256. """
+    shapes = [(187, 181), (31, 43), (13, 17), (5, 3)] if cout == 256 else [(131, 129), (31, 43), (13, 17), (5, 3)]
+    run = _pyramid_layer(64, cout, shapes, 2, seed=cout + tile)
+    rc0, base, d = run(128128)
+    assert rc0 == 0 and torch.isfinite(base).all()
+    tiles, count = (ctypes.c_int * 64)(), ctypes.c_int(0)
+    hip.check(hip.lib().gpp_conv2d_tile_candidates(ctypes.byref(d), tiles, 64, ctypes.byref(count)), 'gpp_conv2d_tile_candidates')
+    assert tile in list(tiles[:count.value])
+    rc, got, _ = run(tile)
+    assert rc == 0, rc
+    assert torch.equal(got.view(torch.int32), base.view(torch.int32))
+    rc, big, _ = run(1256256)
+    assert rc == 0 and torch.equal(big.view(torch.int32), base.view(torch.int32))
+
+
+def test_mixed_height_grid_declines_layers_it_cannot_help():
+    """ no whole round of 256 workgroups fits the first map, or the mix costs as many rounds as the uniform grid: GPP_ERR_UNSUPPORTED,
+    which the autotuner skips -- never a silently different grid """
+    run = _pyramid_layer(64, 256, [(40, 50), (13, 17)], 2, seed=5)
+    rc, _, _ = run(3256224)
+    assert rc == -4
+
+
+def test_f16x3_range_ledger_counts_what_the_half_range_alters_and_keeps_non_finite_values():
+    """ gpp_x3_range_events: zero on ordinary data; an activation an epilogue has to clamp (finite beyond +-65504), an inf or a NaN is
+    counted, and a non-finite value is still non-finite after the split (it is not laundered into +-65504) """
+    lib = hip.lib()
+    n = ctypes.c_uint64(0)
+    c = [c for c in CASES if c[0] == '3x3'][0]
+    c = c[:10] + (False, None, c[12])                                         # no ReLU (it would hide a NaN: max(NaN, 0) = 0), no shortcut
+    for flags in (2, 3):                                                       # pre-split output; pre-split input too
+        make, out, ref, kdepth, keep, _ = build(c, flags=flags)
+        hip.check(lib.gpp_x3_range_events(ctypes.byref(n), 1))
+        C.run_conv(make(128128))
+        hip.check(lib.gpp_x3_range_events(ctypes.byref(n), 0))
+        assert n.value == 0                                                    # nothing out of range: nothing counted
+        bias = keep[5]
+        saved = bias.clone()
+        bias[3] = 1.0e9                                                        # every pixel of channel 3 overflows the half range
+        bias[9] = float('nan')
+        bias[17] = float('inf')
+        C.run_conv(make(128128))
+        hip.check(lib.gpp_x3_range_events(ctypes.byref(n), 1))
+        got = out.read().cpu()
+        pixels = got.shape[0] * got.shape[1] * got.shape[2]
+        assert pixels <= n.value <= 3 * pixels                                 # events are per 8-channel group: channels 3 | 9 | 17 are three groups
+        assert bool((got[..., 3] == 65504.0).all())                            # clamped, and counted
+        assert bool(torch.isnan(got[..., 9]).all()) and bool((~torch.isfinite(got[..., 17])).all())
+        ok = [ch for ch in range(got.shape[-1]) if ch not in (3, 9, 17)]
+        assert torch.isfinite(got[..., ok]).all()
+        bias.copy_(saved)
+        hip.check(lib.gpp_x3_range_events(ctypes.byref(n), 0))
+        assert n.value == 0                                                    # reset

@@ -69,7 +69,8 @@ def test_reference_bars_compare_counts_and_need_detections_in_range():
     assert led['union'] == led['common'] == led['same_plane'] == led['same_orientation'] == 160
     assert led['same_plane_within_100m'] + led['same_plane_beyond_100m'] == 160 and ledger.meets_reference_bars(led)
     # one detection of 160 000 would vanish in a ratio rounded to six digits; the counts see it
-    near_miss = dict(led, common=159999, union=160000, same_plane=159999, same_orientation=159999, detection_set_agreement=1.0)
+    near_miss = dict(led, common=159999, union=160000, same_plane=159999, same_orientation=159999, detection_set_agreement=1.0,
+                     set_differences=1, set_differences_unexplained=1)
     assert not ledger.meets_reference_bars(near_miss)
     # no detection inside the working range: the corner bar has not been met, it has not been measured
     o_far = [x.copy() for x in o]
@@ -98,3 +99,34 @@ def test_the_bar_beyond_100m_scales_with_the_square_of_the_distance():
     o3[5][0, 0] += np.float32(5.0)                                                  # 5 m at 1 km = 5e-2 scaled: far outside
     assert ledger.parity_ledger(o, a, p, o3, a, p)['max_corner_dev_scaled_beyond_100m'] > 1e-3
     assert not ledger.meets_reference_bars(ledger.parity_ledger(o, a, p, o3, a, p))
+
+
+def test_a_set_difference_at_a_tie_of_the_top_k_cut_is_told_from_a_real_one():
+    o, a, p = fake_run(valid=100)                                          # full lists: the cut is the 100th score
+    o2 = [x.copy() for x in o]
+    a2 = a.copy()
+    a2[0, 99] = 77777                                                      # another anchor in the last place, its score the same to 1e-7
+    o2[2][0, 99] = o[2][0, 99] + np.float32(1e-7)
+    led = ledger.parity_ledger(o, a, p, o2, a2, p)
+    assert led['set_differences'] == 2 and led['set_differences_at_a_tie'] == 2 and led['set_differences_unexplained'] == 0
+    assert ledger.meets_reference_bars(led)                                # decided by rounding noise: in the reference as much as here
+    a3 = a.copy()
+    a3[0, 50] = 88888                                                      # a detection from the middle of the list replaced: not a tie
+    led = ledger.parity_ledger(o, a, p, o, a3, p)
+    assert led['set_differences'] == 2 and led['set_differences_at_a_tie'] == 0 and not ledger.meets_reference_bars(led)
+    o4, a4, p4 = fake_run(valid=80)                                        # lists that are not full have no cut: nothing is a tie
+    a5 = a4.copy()
+    a5[0, 79] = 99999
+    assert ledger.parity_ledger(o4, a4, p4, o4, a5, p4)['set_differences_at_a_tie'] == 0
+
+
+def test_pair_bars_are_twice_the_metre_bars():
+    o, a, p = fake_run()
+    o2 = [x.copy() for x in o]
+    near = np.abs(o[5]).reshape(2, 100, -1).max(axis=2) <= 60.0
+    b, dts = np.nonzero(near[:, :80])
+    o2[5][b[0], dts[0]] += np.float32(1.5e-3)                              # 1.5 mm on a detection inside the working range
+    led = ledger.parity_ledger(o, a, p, o2, a, p)
+    assert 1.2e-3 < led['max_keypoint_dev_m_within_100m'] < 1.8e-3
+    if led['max_corner_dev_m_within_100m'] <= 2e-3:
+        assert not ledger.meets_reference_bars(led) and ledger.meets_reference_bars(led, pair=True)

@@ -103,3 +103,53 @@ def test_hip_polling_empty_and_bad_arguments():
     with pytest.raises(ValueError):
         gpp_utils.fit_road_planes(np.zeros((1, 4, 12), np.float32), np.zeros((1, 4, 3), np.float32),
                                   np.zeros((1, 4), np.int32), np.zeros((1, 4, 3), np.float32), planes[:0])
+
+
+def test_padding_rows_are_polled_once_per_run_and_keep_the_reference_bytes(oracle_lib):
+    """ rows with the exact -1 padding of FilterDetections give the same result for every padding row of an image: the kernel polls
+    the first row of a run and copies.  Runs at the end (the usual case), in the middle, at the start, whole images of padding, a
+    single valid row, and rows that LOOK like padding (orientation -1) but are not -- all against the oracle, which polls every row """
+    planes = synthetic.load_plane_database('1k').astype(np.float32)
+    d = synthetic.synthetic_polling_batch(planes, batch=5, num_dets=40, num_valid=40, seed=11)
+
+    def pad(b, rows):
+        d['boxes'][b, rows] = -1.0
+        d['dimensions'][b, rows] = -1.0
+        d['orientations'][b, rows] = -1
+
+    pad(0, slice(7, 40))                                  # 7 detections + 33 padding rows
+    pad(1, slice(0, 5)); pad(1, slice(20, 23)); pad(1, slice(39, 40))      # runs at the start, in the middle, a single row at the end
+    pad(2, slice(0, 40))                                  # nothing detected
+    pad(3, slice(1, 40))                                  # one detection
+    d['orientations'][4, 10:14] = -1                      # orientation -1 with real boxes: not padding, polled as the reference would
+    d['boxes'][4, 20] = -1.0; d['dimensions'][4, 20] = -1.0          # padding boxes with a valid orientation: not padding either
+    d['boxes'][4, 30] = -1.0; d['dimensions'][4, 30] = -1.0; d['orientations'][4, 30] = -1; d['boxes'][4, 30, 11] = -1.5   # almost
+    pad(4, slice(31, 36))
+    for planes_in in (planes, np.tile(planes[None], (5, 1, 1))):
+        ref = helpers.c_oracle_poll(oracle_lib, d['boxes'], d['dimensions'], d['orientations'], d['P_inv'], planes_in)
+        got = gpp_utils.fit_road_planes(d['boxes'], d['dimensions'], d['orientations'], d['P_inv'], planes_in, return_index=True)
+        assert np.array_equal(got[3], ref[3])
+        for a, b in zip(got[:3], ref[:3]):
+            assert helpers.bits_equal(a, b)
+    # and it is the point of the exercise: a frame with 7 detections of 100 costs a fraction of a full one
+    import time
+    import torch
+    full = synthetic.synthetic_polling_batch(synthetic.load_plane_database('10k').astype(np.float32), batch=8, num_dets=100, seed=3)
+    few = {k: v.copy() for k, v in full.items()}
+    few['boxes'][:, 7:] = -1.0; few['dimensions'][:, 7:] = -1.0; few['orientations'][:, 7:] = -1
+    p10k = torch.as_tensor(synthetic.load_plane_database('10k').astype(np.float32)).cuda()
+    times = []
+    for batch in (full, few):
+        args = [torch.as_tensor(batch[k]).cuda() for k in ('boxes', 'dimensions', 'orientations', 'P_inv')] + [p10k]
+        for _ in range(3):
+            gpp_utils.fit_road_planes(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gpp_utils.fit_road_planes(*args)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / 20)
+    print('polling 8 x 100 rows x 10k planes: all valid {:.1f} us, 7 valid {:.1f} us'.format(times[0] * 1e6, times[1] * 1e6))
+    # (not 8 / 100 of it: a scan of 10k planes by one workgroup takes ~40 us whatever the other CUs do -- with few detections the
+    # stage is bound by the latency of one scan, not by the number of scans)
+    assert times[1] < 0.7 * times[0]

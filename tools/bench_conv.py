@@ -206,7 +206,10 @@ if __name__ == '__main__':
         for name, shp, cin, cout, k, tile, f32 in (('reg 3x3 512->512', PYR, 512, 512, 3, 1256256, False), ('towers_0 3x3 512->896', PYR, 512, 896, 3, 2256256, False),
                                                    ('cls 3x3 256->256', PYR, 256, 256, 3, 1192256, False), ('P3 3x3 512->512', PYR[:1], 512, 512, 3, 1192256, False),
                                                    ('reg_ops 3x3 512->144', PYR, 512, 144, 3, 1128160, True), ('dim 3x3 128->128', PYR, 128, 128, 3, 1192128, False),
-                                                   ('cls_out 3x3 256->96 t192x128', PYR, 256, 96, 3, 1192128, True), ('cls_out 3x3 256->96 t192x96', PYR, 256, 96, 3, 1192096, True)):
+                                                   ('cls_out 3x3 256->96 t192x128', PYR, 256, 96, 3, 1192128, True), ('cls_out 3x3 256->96 t192x96', PYR, 256, 96, 3, 1192096, True),
+                                                   # the mixed-height grids (round 4) beside the uniform ones above, same run, same box
+                                                   ('reg mix 256+224', PYR, 512, 512, 3, 3256224, False), ('reg 192x256', PYR, 512, 512, 3, 1192256, False),
+                                                   ('P3 mix 192+160', PYR[:1], 512, 512, 3, 3192160, False), ('P3 256x256', PYR[:1], 512, 512, 3, 1256256, False)):
             total = sum(h * w for h, w in shp)
             wk = (torch.randn((k, k, cin, cout)) * 0.02).numpy()
             w = C.pack_weight(wk, dtype, dev)
