@@ -183,7 +183,7 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 // The block tiles a layer may run with (same K order per output element in every one of them: the choice never changes a result).
 // One list for the autotuner below and for gpp_conv2d_tile_candidates (tests draw tiles at random from it).
 static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
-                             1128128, 1192128, 1128256, 1192256, 256256, 1256256,
+                             1128128, 1192128, 1128256, 1160256, 1192256, 1224256, 256256, 1256256,
                              128160, 192160, 1192160, 1128160, 2256256, 1192096, 3256224, 3192160,
                              128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
 // (the loader-wavefront form of round 2, tile codes 3064128 ..., measured 1.5 - 2x slower on every layer it was built for
@@ -207,7 +207,7 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
     // the pipelined loops need a few K-steps to pay; 16-bit types, and GPP_BF16X3 on a pre-split input map
     const bool x3_pipe = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);
     if (tile > 1000000 && tile < 3000000 && (nk < 4 || (f32_storage(desc->dtype) && !x3_pipe))) return false;
-    if (tile == 1256256 && !x3_pipe) return false;
+    if ((tile == 1256256 || tile == 1160256 || tile == 1224256) && !x3_pipe) return false;
     if (x3_pipe && tile == 1192160) return false;
     if (bn == 256 && desc->dtype == GPP_F32) return false;
     if ((tile == 128256 || tile == 192256) && !is_x3(desc->dtype)) return false;

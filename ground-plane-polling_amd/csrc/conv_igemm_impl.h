@@ -2114,7 +2114,9 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                         // the software-pipelined three-phase loop: pre-split input maps only (1000000 + tile, as for the 16-bit types)
                         switch (d.tile_hint) {
                             case 1256256: return launch<DT, 256, 256, 2, 4, 2, true, true>(d, st);
+                            case 1224256: return launch<DT, 224, 256, 2, 4, 2, true, true>(d, st);      // (224 / 160 rows: staged as 256 / 192, see BMS)
                             case 1192256: return launch<DT, 192, 256, 2, 4, 2, true, true>(d, st);
+                            case 1160256: return launch<DT, 160, 256, 2, 4, 2, true, true>(d, st);
                             case 1128256: return launch<DT, 128, 256, 2, 4, 2, true, true>(d, st);
                             case 1192128: return launch<DT, 192, 128, 2, 2, 2, true, true>(d, st);
                             case 1128128: return launch<DT, 128, 128, 2, 2, 2, true, true>(d, st);
@@ -2132,7 +2134,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                 }
                 switch (d.tile_hint) {
                     case 256: case 1128128: case 1192128: case 1128256: case 1192256: case 1192160: case 1128160: case 2256256: case 512: case 256256: case 1256256:
-                    case 192256: case 128256: case 1192096: case 3256224: case 3192160:
+                    case 192256: case 128256: case 1192096: case 3256224: case 3192160: case 1224256: case 1160256:
                         return GPP_ERR_UNSUPPORTED;
                     default: return GPP_ERR_BAD_ARG;
                 }

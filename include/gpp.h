@@ -157,7 +157,7 @@ typedef struct gpp_conv_desc {
                                        (C_out = 256 k + 128 only); legacy codes 64 / 128 / 256 / 512; anything else: GPP_ERR_BAD_ARG.
                                        GPP_BF16X3 / GPP_F16X3 (the same tile set, the same loops): the plain tiles, 128256 / 192256 / 256256
                                        (8 wavefronts), and on a pre-split input map (x3_split & GPP_X3_IN) the pipelined 1128128, 1192128,
-                                       1128256, 1192256, 1256256, 1128160, 1192096 and 2256256; 192160 exists on pre-split inputs only;
+                                       1128256, 1160256, 1192256, 1224256, 1256256, 1128160, 1192096 and 2256256; 192160 exists on pre-split inputs only;
                                        3256224 / 3192160 (3000000 + BMA * 1000 + BMB, C_out % 256 == 0, pre-split inputs): 256-column tiles
                                        of two heights in ONE grid -- whole rounds of BMA-row tiles, the rest in BMB-row tiles -- against the
                                        round quantisation of one-workgroup-per-CU tiles (GPP_ERR_UNSUPPORTED where it gains nothing).

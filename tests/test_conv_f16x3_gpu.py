@@ -26,7 +26,7 @@ from test_conv_f32_gpu import reference64
 pytestmark = pytest.mark.gpu
 
 PLAIN_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128, 128160, 128256, 192256, 256256]
-PIPE_TILES = [1128128, 1192128, 1128256, 1192256, 1256256, 1128160, 1192096]
+PIPE_TILES = [1128128, 1192128, 1128256, 1160256, 1192256, 1224256, 1256256, 1128160, 1192096]
 
 
 def held(t):
