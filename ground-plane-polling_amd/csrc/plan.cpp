@@ -37,8 +37,7 @@ struct Lanes {
         // only "short latency-bound chains", and letting their workgroups in first cost 0.6 % of the f16x3 step (808 -> 813 images/s,
         // same box, alternating); GPP_LANE_PRIORITY=high restores the highest priority (read once, when the device's lanes are made)
         const char* pr = getenv("GPP_LANE_PRIORITY");
-        const int prio = (pr && !strcmp(pr, "high")) ? hi : 0;
-        (void)lo;
+        const int prio = (pr && !strcmp(pr, "high")) ? hi : (pr && !strcmp(pr, "low")) ? lo : 0;
         for (int l = 0; l < kLanes; ++l) {
             hipError_t e = hipStreamCreateWithPriority(&stream[l], hipStreamNonBlocking, prio);
             if (e != hipSuccess) return (int)e;

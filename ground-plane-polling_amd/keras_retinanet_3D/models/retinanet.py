@@ -100,6 +100,7 @@ class Plan(object):
         self.oracle_names = {}  # fused ops: reference layer name of each output map (per-layer parity tests)
         self.lanes = []         # per op: side-stream lane << 8 | join flag (include/gpp.h GPP_OP_LANE / GPP_OP_JOIN)
         self.op_batch = {}      # id(descriptor) -> images the launch covers where that is not the plan's batch (half-batch launches)
+        self.access = {}        # id(descriptor) -> (byte intervals read, byte intervals written): check_stream_ordering
         self.array = None
         self.flops = 0.0
 
@@ -108,6 +109,61 @@ class Plan(object):
         self.ops.append((kind, tag, desc, name, flops))
         self.lanes.append((int(lane) << 8) | (OP_JOIN if join else 0) | (OP_SYNC if sync else 0))
         self.flops += flops
+
+    # ---- who reads and writes what: the byte intervals (one per image) every launch touches, by descriptor.  check_stream_ordering()
+    # replays gpp_plan_run's fork / join rules over them: the plan builder places launches on side streams by hand, and a missing
+    # join is a race that shows up once in a while, at full size only (round 4 found one between a split and an unsplit stage)
+    @staticmethod
+    def span(fm, esz=None):
+        """ byte intervals of an FMap, one per image """
+        e = fm.buf.element_size() if esz is None else esz
+        base = fm.buf.data_ptr() + fm.off * e
+        size = ((fm.H * fm.W - 1) * fm.pitch + fm.C) * e
+        return [(base + b * fm.bstride * e, base + b * fm.bstride * e + size) for b in range(fm.B)]
+
+    @staticmethod
+    def span_of(tensor):
+        return [(tensor.data_ptr(), tensor.data_ptr() + tensor.numel() * tensor.element_size())]
+
+    def touch(self, desc, reads=(), writes=(), kind=None):
+        """ kind: for descriptors shared by several ops (the three decode stages), the op kind the accesses belong to """
+        self.access[id(desc) if kind is None else (id(desc), kind)] = ([iv for r in reads for iv in r], [iv for w in writes for iv in w])
+
+    def check_stream_ordering(self):
+        """ every pair of launches on DIFFERENT streams that touch overlapping bytes (at least one of them writing) must be ordered by a
+        fork or a join, as gpp_plan_run (csrc/plan.cpp) places them: a side-lane launch forks from the caller's stream when its lane is
+        not open (or carries SYNC); a JOIN launch on the caller's stream (and the end of the plan) closes every open lane.
+        Returns the list of violations [(earlier op, later op)], empty when the plan is race-free by construction. """
+        def overlap(a, b):
+            return any(x0 < y1 and y0 < x1 for x0, x1 in a for y0, y1 in b)
+        bad, seen = [], []                    # seen: (position, lane, name, reads, writes)
+        active = {}
+        forks, joins = {}, []                 # lane -> positions of its forks; positions of joins
+        for pos, (kind, _, desc, name, _) in enumerate(self.ops):
+            flags = self.lanes[pos]
+            lane, join, sync = (flags >> 8) & 0xff, bool(flags & OP_JOIN), bool(flags & OP_SYNC)
+            if lane > 0:
+                if not active.get(lane) or sync:
+                    forks.setdefault(lane, []).append(pos)
+                    active[lane] = True
+            elif join:
+                joins.append(pos)
+                active = {}
+            reads, writes = self.access.get((id(desc), kind)) or self.access.get(id(desc), ((), ()))
+            for p0, l0, n0, r0, w0 in seen:
+                if l0 == lane or not (overlap(w0, reads) or overlap(w0, writes) or overlap(r0, writes)):
+                    continue
+                j = [q for q in joins if p0 < q <= pos]                      # a join after the earlier launch, not after this one
+                if l0 == 0:
+                    ok = any(p0 < f <= pos for f in forks.get(lane, []))     # this lane forked after the main-stream launch
+                elif lane == 0:
+                    ok = bool(j)
+                else:
+                    ok = bool(j) and any(min(j) <= f <= pos for f in forks.get(lane, []))
+                if not ok:
+                    bad.append((n0, name))
+            seen.append((pos, lane, name, reads, writes))
+        return bad
 
     def finalize(self):
         arr = (PlanOp * len(self.ops))()
@@ -210,6 +266,7 @@ class RetinaNet3D(object):
         plan.add(OP_CONV, d, name, tag=tag, flops=C.conv_flops(d), lane=lane, join=join, sync=sync)
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
         plan.io_parts.setdefault(name, []).append((inputs, outputs, residuals))
+        plan.touch(d, [Plan.span(f) for f in list(inputs) + list(residuals or [])], [Plan.span(f, 4 if out_f32 else None) for f in outputs])
 
     def _tail(self, plan, nm, a, y, shortcut, join=False, lane=0):
         """ branch2b (3x3) + branch2c (1x1, + shortcut, ReLU) of one bottleneck as ONE launch
@@ -223,6 +280,7 @@ class RetinaNet3D(object):
         plan.add(OP_TAIL, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2), join=join, lane=lane)
         plan.io[name] = ([a], [y], [shortcut])
         plan.io_parts.setdefault(name, []).append(([a], [y], [shortcut]))
+        plan.touch(t, [Plan.span(a), Plan.span(shortcut)], [Plan.span(y)])
 
     def _build(self, B, H, Wd, n_planes, planes_batched):
         torch, dev, dt = self.torch, self.device, self.tdtype
@@ -264,14 +322,18 @@ class RetinaNet3D(object):
             d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), x.buf.data_ptr(),
                          C.gpp_storage_dtype(self.dtype), B, H, Wd)
             plan.add(OP_STEM_POOL, d, 'conv1+pool1', flops=2.0 * B * H1 * W1 * 147 * 64)
+            plan.touch(d, [Plan.span_of(plan.images)], [Plan.span(x)])
             plan.stem_out = None
         else:
             stem = fmap(H1, W1, 64)
             d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
                          hip.GPP_F16X3 if getattr(self, 'stem_x3', False) else C.gpp_storage_dtype(self.dtype), B, H, Wd)
             plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
+            plan.touch(d, [Plan.span_of(plan.images)], [Plan.span(stem)])
             plan.stem_out = stem
-            plan.add(OP_MAXPOOL, PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_storage_dtype(self.dtype), B, H1, W1, 64, 0), 'pool1')
+            pool_d = PoolDesc(stem.buf.data_ptr(), x.buf.data_ptr(), C.gpp_storage_dtype(self.dtype), B, H1, W1, 64, 0)
+            plan.add(OP_MAXPOOL, pool_d, 'pool1')
+            plan.touch(pool_d, [Plan.span(stem)], [Plan.span(x)])
         plan.pool_out = x
 
         # ---- bottleneck stages (keras_resnet bottleneck_2d: stride on the first 1x1).
@@ -294,6 +356,8 @@ class RetinaNet3D(object):
             return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch, split=fm.split, half=fm.half)
 
         feats = []
+        lane_open = False            # a stage that ran as two half batches leaves its second half on side lane 1: whatever reads the whole
+        #                              batch next (a stage that is NOT split, or the FPN) has to join it first
         for stage, n_blocks in enumerate(W.BLOCKS[self.backbone_name]):
             f = 64 * 2 ** stage
             blocks = []
@@ -323,11 +387,14 @@ class RetinaNet3D(object):
                     a_, y_ = sub(rec['a'], c0, nb), sub(rec['y'], c0, nb)
                     # the projection shortcut of a stage's first block is independent of branch2a / 2b: on a side stream it runs beside them
                     # and branch2c (or the fused tail) joins it (GPP_BR1_LANE=0: serial, behind branch2a)
-                    side = br1_lane and rec['sc'] is not None and not halves
+                    join_halves = lane_open and not halves       # first launch of a whole-batch stage behind a split one
+                    side = br1_lane and rec['sc'] is not None and not halves and not join_halves
                     if side:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=1)
-                    self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True, lane=ln)
+                    self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True, lane=ln, join=join_halves)
+                    if join_halves:
+                        lane_open = False
                     if rec['sc'] is not None and not side:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=ln)
@@ -340,6 +407,7 @@ class RetinaNet3D(object):
                         self._conv(plan, 'res{}_branch2b'.format(nm), [a_], [b_], 3, pad=(1, 1), relu=True, lane=ln)
                         self._conv(plan, 'res{}_branch2c'.format(nm), [b_], [y_], 1, relu=True, residuals=[sc_], join=side, lane=ln)
                     xs_of[c0] = y_
+            lane_open = lane_open or halves
             feats.append(x)
         _, C3, C4, C5 = feats
         plan.features = {'stem': plan.stem_out, 'C2': feats[0], 'C3': C3, 'C4': C4, 'C5': C5}
@@ -377,12 +445,14 @@ class RetinaNet3D(object):
         # fused first tower layer (GPP_FPN_LANES=0: serial)
         fpn_lanes = head_lanes or os.environ.get('GPP_FPN_LANES', '1') != '0'      # measured +0.8 % on the f16x3 step
         l_p5, l_p6 = (1, 2) if fpn_lanes else (0, 0)
-        self._conv(plan, 'C5_reduced', [C5], [T5], 1, join=bool(half_stages))
+        self._conv(plan, 'C5_reduced', [C5], [T5], 1, join=lane_open)
         self._conv(plan, 'P5', [T5], [P[2]], 3, pad=(1, 1), lane=l_p5)
         self._conv(plan, 'P6', [C5], [P[3]], 3, stride=2, pad=(C.same_pad(C5.H, 3, 2)[1], C.same_pad(C5.W, 3, 2)[1]), lane=l_p6)
         R6 = smap(shapes[3][0], shapes[3][1], 512)
-        plan.add(OP_RELU, ReluDesc(pyr.data_ptr() + P[3].off * self.esz, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
-                                   pix[3] * 512, C.gpp_dtype(self.dtype) if x3s else C.gpp_storage_dtype(self.dtype), B), 'C6_relu', lane=l_p6)
+        relu_d = ReluDesc(pyr.data_ptr() + P[3].off * self.esz, R6.buf.data_ptr(), P[3].bstride, R6.bstride,
+                          pix[3] * 512, C.gpp_dtype(self.dtype) if x3s else C.gpp_storage_dtype(self.dtype), B)
+        plan.add(OP_RELU, relu_d, 'C6_relu', lane=l_p6)
+        plan.touch(relu_d, [Plan.span(P[3])], [Plan.span(R6)])
         plan.relu_io = (P[3], R6)
         self._conv(plan, 'P7', [R6], [P[4]], 3, stride=2,
                    pad=(C.same_pad(shapes[3][0], 3, 2)[1], C.same_pad(shapes[3][1], 3, 2)[1]), lane=l_p6)
@@ -477,6 +547,15 @@ class RetinaNet3D(object):
                         plan.labels.data_ptr(), plan.orientations.data_ptr(), plan.anchor_index.data_ptr(),
                         plan.counts.data_ptr(), plan.detect_ws.data_ptr(), plan.detect_ws.numel(), plan.n_anchors,
                         B, anchor_utils.NUM_BASE_ANCHORS, 1, D, SCORE_THRESHOLD, NMS_THRESHOLD if self.nms else 2.0)
+        # what the decode stages touch (one shared descriptor: logged per op kind)
+        sp = Plan.span_of
+        det_out = [sp(t) for t in (plan.boxes, plan.dimensions, plan.scores, plan.labels, plan.orientations, plan.anchor_index)]
+        heads_in = [sp(plan.cls_logits), sp(plan.regression), sp(plan.regression_dim)]
+        plan.touch(dd, [sp(plan.cls_logits)], [sp(plan.detect_ws), sp(plan.counts)], kind=OP_DETECT_CANDIDATES)
+        plan.touch(dd, [sp(plan.detect_ws), sp(plan.regression)], [sp(plan.detect_ws)], kind=OP_DETECT_SELECT)
+        plan.touch(dd, heads_in + [sp(plan.detect_ws)], det_out, kind=OP_DETECT_EMIT)
+        for whole in (OP_DETECT, OP_DETECT_OSF):
+            plan.touch(dd, heads_in, det_out + [sp(plan.detect_ws), sp(plan.counts)], kind=whole)
         if overlap:
             # spliced in where their inputs are complete (the descriptors need the buffers allocated above)
             at = detect_at['select']
@@ -501,6 +580,8 @@ class RetinaNet3D(object):
                       plan.best_index.data_ptr(), plan.poll_ws.data_ptr(), plan.poll_ws.numel(), B, D, n_planes,
                       int(planes_batched), POLL_THRESHOLD, 0)
         plan.add(OP_POLL, pd, 'fit_road_planes', tag=2, flops=162.0 * B * D * n_planes)      # tag 2: bench.py times it live too
+        plan.touch(pd, [Plan.span_of(t) for t in (plan.boxes, plan.dimensions, plan.orientations, plan.P_inv, plan.planes)],
+                   [Plan.span_of(t) for t in (plan.keypoints, plan.keyplanes, plan.residuals, plan.best_index, plan.poll_ws)])
         plan.workspaces = {lane: torch.empty((max(need_, 16),), dtype=torch.uint8, device=dev) for lane, need_ in plan.ws_need.items()}
         for d, lane in plan.conv_descs:
             d.partial = plan.workspaces[lane].data_ptr()

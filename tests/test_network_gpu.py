@@ -218,6 +218,67 @@ def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
             assert helpers.bits_equal(a, b)
 
 
+PLAN_OPTIONS = [{}, {'GPP_HALF_LANES': '1,2'}, {'GPP_HALF_LANES': '1'}, {'GPP_HALF_LANES': '2'}, {'GPP_HALF_LANES': '0,1,2,3'}, {'GPP_HALF_LANES': '0,2'},
+                {'GPP_HALF_LANES': ''}, {'GPP_BR1_LANE': '0'}, {'GPP_FPN_LANES': '0'}, {'GPP_P4_LANE': '0'}, {'GPP_HEAD_LANES': '1'},
+                {'GPP_DECODE_OVERLAP': '0'}, {'GPP_STAGE_CHUNKS': '4,8,8,8'}, {'GPP_STAGE_CHUNKS': '2,4,8,8', 'GPP_HALF_LANES': '2,3'},
+                {'GPP_HALF_LANES': '3', 'GPP_FPN_LANES': '0', 'GPP_BR1_LANE': '0'}]
+
+
+@pytest.mark.parametrize('options', PLAN_OPTIONS, ids=[' '.join('{}={}'.format(*kv) for kv in o.items()) or 'default' for o in PLAN_OPTIONS])
+def test_every_plan_variant_orders_its_streams_and_gives_the_same_bytes(options, monkeypatch):
+    """ The plan builder puts launches on side streams by hand (half batches of res3-res5, projection shortcuts, small FPN launches,
+    the detection selection).  Plan.check_stream_ordering replays gpp_plan_run's fork / join rules over the bytes every launch reads and
+    writes: two launches on different streams that touch the same bytes (one of them writing) must have a fork or a join between
+    them.  Round 4 found a missing join this way of thinking would have caught: a stage that ran as two half batches followed by one
+    that did not (GPP_HALF_LANES=1,2) read the second half's maps unjoined -- a race that only showed at full size, and only in a
+    non-default configuration the earlier rounds had used for timing.  Every switch the builder has is checked here, and each variant
+    must return the bytes of the one-stream plan. """
+    planes = synthetic.load_plane_database('100').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    x = images(4, 200, 333, seed=12)
+    P = np.tile(P_inv[None].astype(np.float32), (4, 1, 1))
+    inputs = [x, P, np.tile(planes[None], (4, 1, 1))]
+
+    def run(env):
+        for k in ('GPP_HALF_LANES', 'GPP_BR1_LANE', 'GPP_FPN_LANES', 'GPP_P4_LANE', 'GPP_HEAD_LANES', 'GPP_DECODE_OVERLAP', 'GPP_STAGE_CHUNKS'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='f16x3')
+        out = model.predict_on_batch(inputs)
+        plan = model.plan_for(4, 200, 333, planes.shape[0], True)
+        extra = [plan.cls_logits.cpu().numpy(), plan.regression.cpu().numpy(), plan.regression_dim.cpu().numpy()]
+        return out + extra, plan
+
+    got, plan = run(options)
+    assert plan.check_stream_ordering() == []
+    serial, splan = run({'GPP_HALF_LANES': '', 'GPP_BR1_LANE': '0', 'GPP_FPN_LANES': '0', 'GPP_DECODE_OVERLAP': '0'})
+    assert splan.check_stream_ordering() == [] and all((f >> 8) & 0xff == 0 for f in splan.lanes)        # everything on the caller's stream
+    for a, b in zip(got, serial):
+        assert helpers.bits_equal(a, b)
+
+
+def test_the_stream_ordering_check_sees_a_missing_join(monkeypatch):
+    """ the checker itself: take the join away from the launch that consumes the half-batch lanes, or the fork (SYNC) from a side launch
+    that reads what the main stream has just written, and it says so """
+    from keras_retinanet_3D.models import retinanet as R
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='f16x3')
+    plan = model.plan_for(4, 200, 333, 100, True)
+    assert plan.check_stream_ordering() == []
+    names = [op[3] for op in plan.ops]
+    i = names.index('C5_reduced')
+    assert plan.lanes[i] & R.OP_JOIN
+    saved = plan.lanes[i]
+    plan.lanes[i] &= ~R.OP_JOIN
+    bad = plan.check_stream_ordering()
+    assert bad and any(later == 'C5_reduced' for _, later in bad)
+    plan.lanes[i] = saved
+    i = names.index('P4')
+    assert plan.lanes[i] & R.OP_SYNC
+    plan.lanes[i] &= ~R.OP_SYNC
+    assert any(later == 'P4' for _, later in plan.check_stream_ordering())
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'f16x3'])
 def test_random_tiles_never_change_a_byte(dtype, monkeypatch):
     """ GPP_TUNE_RANDOM: every conv layer (and fused tail) of the plan takes a RANDOM tile among the autotuner's candidates
