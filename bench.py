@@ -229,6 +229,8 @@ def tile_name(code):
         return {64: '128x64', 128: '128x128', 256: '256x128 (3-deep ring)', 512: '256x256 pipelined'}[code]
     if code // 1000000 == 2:
         return '256x256 + 512x128 dual grid'
+    if code // 1000000 == 3:
+        return '{0}x256 + {1}x256 mixed-height grid pipelined'.format((code // 1000) % 1000, code % 1000)
     bm, bn = (code // 1000) % 1000, code % 1000
     return '{}x{}{}'.format(bm, bn, ' pipelined' if code // 1000000 == 1 else '')
 
@@ -582,7 +584,8 @@ def main():
                                          'algorithmic {} MB for {})'.format(ALGORITHMIC_MB[args.dtype], args.dtype),
                          'algorithmic_mb_per_launch': ALGORITHMIC_MB[args.dtype],
                          'kernel': 'conv_igemm_kernel<{}> tile {} on pyramid_regression_1..3 (3x3, 512->512, 5 levels, M={})'.format(
-                             args.dtype, tile_name(reg_tile), B * (plan.n_anchors // 12)),
+                             args.dtype, ' / '.join(sorted(set(tile_name(getattr(plan, 'tuning', {}).get('pyramid_regression_{}'.format(i), (0, 0.0))[0])
+                                                               for i in (1, 2, 3)))), B * (plan.n_anchors // 12)),
                          'gflop_per_launch': round(flops_per_launch / 1e9, 1), 'mean_launch_ms': round(mean_ms, 4),
                          'launches_timed': len(durations), 'timed_on_steps': 'every {}rd of the {} timed steps'.format(EVENT_EVERY, args.steps),
                          'library': version},

@@ -1609,7 +1609,7 @@ int prepare(gpp_conv_desc& d)
 // are pre-split (x3_split: d1 GPP_X3_IN; d2 GPP_X3_OUT | GPP_X3_RES); the 69 MB (res2, B = 8) intermediate map is never written.
 // LDS: max(two phase-1 stages, intermediate tile + one 128-row tile of W2) -- 64 KB for C = 64 at 128 rows: two workgroups per CU.
 template <int DT, int BM, int CMID>
-__global__ __launch_bounds__(256, 2) void bottleneck_tail_x3_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2)
+__global__ __launch_bounds__(256, (BM <= 64 ? 3 : 2)) void bottleneck_tail_x3_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2)
 {
     static_assert(kX3<DT>, "x3 types");
     using xh8 = typename X3Half<DT>::vec;
@@ -2209,6 +2209,7 @@ int dispatch_tail_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStr
 {
     if (d1.C_in != 64) return GPP_ERR_UNSUPPORTED;
     switch (tile_rows) {
+        case 64: return launch_tail_x3<DT, 64, 64>(d1, d2, st);        // 48 KB of LDS, <= 168 registers: three workgroups per CU
         case 96: return launch_tail_x3<DT, 96, 64>(d1, d2, st);
         case 0:
         case 128: return launch_tail_x3<DT, 128, 64>(d1, d2, st);

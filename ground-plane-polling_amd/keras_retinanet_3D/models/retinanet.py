@@ -670,7 +670,7 @@ class RetinaNet3D(object):
                     desc.tile_hint = rnd.choice(ok)
                     plan.tuning[name] = (int(desc.tile_hint), 0.0)
                 else:
-                    desc.tile_rows = rnd.choice((96, 128, 160))
+                    desc.tile_rows = rnd.choice((64, 96, 128, 160) if self.dtype in C.X3_TYPES else (96, 128, 160))
                     plan.tuning[name] = (int(desc.tile_rows), 0.0)
                 self.run_op(plan, index)
                 continue
@@ -678,7 +678,7 @@ class RetinaNet3D(object):
                 key = (name, plan.op_batch.get(id(desc), B), H, Wd)          # (a half-batch launch is tuned as what it is)
                 if key not in self._tuned:
                     times = {}
-                    for rows in (96, 128, 160):
+                    for rows in ((64, 96, 128, 160) if (self.dtype in C.X3_TYPES and os.environ.get('GPP_TAIL64', '1') != '0') else (96, 128, 160)):
                         desc.tile_rows = rows
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         self.run_op(plan, index)

@@ -210,7 +210,8 @@ int gpp_conv2d_tile_candidates(const gpp_conv_desc* host_desc, int* tiles, int c
    resnet.py:88-93): the 3x3 conv "branch2b" (C -> C, C = 64 or 128, stride 1, pad 1, + bias + ReLU) and the 1x1 conv
    "branch2c" (C -> multiple of 128, + bias + residual + ReLU) in ONE launch; the intermediate map stays in LDS.
    conv3x3->out is not written.  Results are bit-identical to gpp_conv2d_igemm(conv3x3) + gpp_conv2d_igemm(conv1x1).
-   tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup.  Other shapes, and GPP_F32: GPP_ERR_UNSUPPORTED. */
+   tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup (the x3 types also 64: three workgroups per CU).  Other shapes,
+   and GPP_F32: GPP_ERR_UNSUPPORTED. */
 int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream);
 
 /* GPP_F16X3 range ledger.  The half type ends at +-65504: an epilogue that stores an activation outside it (a finite value it has to

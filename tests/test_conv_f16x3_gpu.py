@@ -318,7 +318,7 @@ def test_f16x3_arguments_are_validated():
     assert hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) == 0
 
 
-@pytest.mark.parametrize('tile_rows', [0, 96, 128, 160])
+@pytest.mark.parametrize('tile_rows', [0, 64, 96, 128, 160])
 @pytest.mark.parametrize('dtype', ['f16x3', 'bf16x3'])
 @pytest.mark.parametrize('B,H,W', [(2, 25, 31), (1, 7, 5), (3, 9, 40), (1, 101, 67)])
 def test_x3_bottleneck_tail_equals_the_two_layers(B, H, W, dtype, tile_rows):
@@ -384,7 +384,7 @@ def test_x3_bottleneck_tail_needs_pre_split_maps_and_64_channels():
     d1, d2, keep2 = layer_pair(128, True)                      # C = 128: one workgroup per CU, not built
     assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 0, hip.stream_ptr()) == -4
     d1, d2, keep3 = layer_pair(64, True)
-    assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 64, hip.stream_ptr()) == -1
+    assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 72, hip.stream_ptr()) == -1
     assert hip.lib().gpp_bottleneck_tail(ctypes.byref(d1), ctypes.byref(d2), 0, hip.stream_ptr()) == 0
 
 

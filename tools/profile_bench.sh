@@ -26,11 +26,13 @@ python3 - "$trace" "$code" "$dt" "$xin" > $out/dominant_kernel_trace_summary.txt
 import csv, sys
 code, dt, xin = sys.argv[2], sys.argv[3], sys.argv[4]
 rows = [r for r in csv.DictReader(open(sys.argv[1]))
-        if 'conv_igemm_kernel<%s, 256, 256, 2, 4, 2, true%s>' % (code, xin) in r['Kernel_Name'] and int(r['Grid_Size_X']) == 722 * 512]
+        if ('conv_igemm_kernel<%s, 256, 256, 2, 4, 2, true%s>' % (code, xin) in r['Kernel_Name'] and int(r['Grid_Size_X']) == 722 * 512) or
+           ('conv_igemm_mix_kernel<%s, 256, 224' % code in r['Kernel_Name'] and int(r['Grid_Size_X']) == 748 * 512)]      # (round 4: the mixed-height grid of the same layer)
+n_mix = sum('mix_kernel' in r['Kernel_Name'] for r in rows)
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 d_all = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows]
 d = d_all[9:39]        # bench.py --steps 10 --warmup 3: launches 10..39 are the 30 of the timed region (the HIP events cover those of steps 0, 3, 6, 9)
-print('conv_igemm_kernel<%s,256,256,2,4,2,pipe>, grid 722 workgroups x 512 threads = the regression-tower layers' % dt)
+print('conv_igemm_kernel<%s,256,256,2,4,2,pipe> (grid 722 x 512 threads) / conv_igemm_mix_kernel<%s,256,224> (512 + 236 workgroups) = the regression-tower layers; %d of %d launches in the mixed form' % (dt, dt, n_mix, len(rows)))
 print('(3x3, 512->512, five pyramid levels, M = 91504, 431.8 GFLOP per launch), from the rocprofv3 kernel trace:')
 print('timed region (30 launches of the 10 timed steps): mean %.1f us  min %.1f us  max %.1f us  ->  %.1f TFLOP/s at the mean' % (sum(d) / len(d), min(d), max(d), 431.8e3 / (sum(d) / len(d))))
 print('all %d launches of the run (tuning-free: warm-up + timed steps): mean %.1f us' % (len(d_all), sum(d_all) / len(d_all)))
