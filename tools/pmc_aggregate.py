@@ -53,7 +53,7 @@ if 'SQ_INSTS_VALU' in mean:
     # SQ_INSTS_VALU / SQ_INSTS_MFMA = 1.0x, profiles/r4/valu_counter_includes_mfma.txt); the vector-ALU work BESIDE the matrix pipe is the difference
     lines.append('SQ_INSTS_VALU / SQ_INSTS_MFMA = %.2f (the counter includes the MFMAs) -> non-MFMA VALU instructions per MFMA = %.2f' % (
         mean['SQ_INSTS_VALU'] / mean['SQ_INSTS_MFMA'], mean['SQ_INSTS_VALU'] / mean['SQ_INSTS_MFMA'] - 1.0))
-    lines.append('(disassembly of the K-step of the 256 x 256 tile: 96 MFMA, 24 ds_read_b128, 8 LDS-DMA, 26 other VALU -- tap masks and LDS addresses -- per wavefront)')
+    lines.append('(disassembly of the K-step of the 256 x 256 tile: 96 MFMA, 24 ds_read_b128, 8 LDS-DMA, 24 other VALU -- tap masks and LDS addresses -- per wavefront)')
 open(out_prefix + '.txt', 'w').write('\n'.join(lines) + '\n')
 json.dump({'kernel': 'conv_igemm_kernel<%s,256,256,2,4,2,pipe>' % dtype, 'dtype': dtype, 'grid': GRID, 'library_version': version, 'traffic_bytes_per_launch': read_b + write_b,
            'read_bytes': read_b, 'write_bytes': write_b, 'algorithmic_bytes': alg_read + alg_write,
