@@ -202,7 +202,9 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
         const bool x3_in = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);
         return x3_in && desc->C_out % 256 == 0 && nk >= 4 && desc->split_k <= 1 && rows * (desc->C_out / 256) >= 256 * 256;
     }
-    if (tile && bn == 64 && desc->C_out > 256) return false;        // narrow tiles on wide layers: never competitive
+    // narrow tiles on wide layers: never competitive -- except on the shallow 1 x 1 layers (K <= 256: a handful of K-steps, bound by the
+    // latency of their few dependent tile loads, where more and smaller workgroups per CU win 3 - 6 %: profiles/r4/hbm_layers_f16x3.txt)
+    if (tile && bn == 64 && desc->C_out > 256 && !(desc->KH == 1 && desc->KW == 1 && desc->C_in <= 256)) return false;
     if (bn == 256 && (desc->C_out < 192 || rows < 256 * 16)) return false;
     // the pipelined loops need a few K-steps to pay; 16-bit types, and GPP_BF16X3 on a pre-split input map
     const bool x3_pipe = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);

@@ -677,6 +677,16 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
     constexpr bool BIASPRE = !PIPE && NF <= 4 && MF * NF <= (DT == GPP_F16X3 ? (XIN ? 16 : 0) : 24);
     if constexpr (BIASPRE) load_bias();
 
+#ifdef GPP_VALU_PAD
+    // experiment (make variant EXTRA=-DGPP_VALU_PAD=n): n extra vector-ALU instructions per wavefront ahead of the main loop -- is a layer
+    // bound by instruction issue?  (profiles/r4/valu_pad_experiment.txt)
+    {
+        int pad = lane;
+#pragma unroll
+        for (int i = 0; i < GPP_VALU_PAD; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad));
+        if (pad == -12345) acc[0][0][0] = 1.0f;
+    }
+#endif
     GPP_STAMP(1);
     // ---- main loop.  Ring of STAGES buffers, PF = STAGES-1 K-steps of LDS-DMA in flight; one raw
     // s_barrier per K-step.  At the top of step ks a counted vmcnt retires this wave's loads of

@@ -72,12 +72,13 @@ for name, h, w, cin, cout, res in LAYERS:
     tiles, count = (ctypes.c_int * 64)(), ctypes.c_int(0)
     hip.check(hip.lib().gpp_conv2d_tile_candidates(ctypes.byref(d), tiles, 64, ctypes.byref(count)), 'candidates')
     rows = []
-    for tile in list(tiles[:count.value]):
+    extra = [t for t in (64064, 96064, 128064, 160064, 192064) if t not in list(tiles[:count.value])]      # narrow tiles the tuner does not offer wide layers
+    for tile in list(tiles[:count.value]) + extra:
         d.tile_hint = tile
         if hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr()) != 0:
             continue
         rows.append((timeit(lambda: C.run_conv(d), True), timeit(lambda: C.run_conv(d), False), tile))
     rows.sort()
     print('{:30s} M {:6d}  {:6.1f} MB algorithmic, {:5.1f} us at 6.3 TB/s'.format(name, B * h * w, nbytes / 1e6, nbytes / 6.3e6))
-    for cold, hot, tile in rows[:4]:
+    for cold, hot, tile in rows[:4] + [r for r in rows[4:] if r[2] in extra]:
         print('      tile {:8d}: cold {:6.1f} us = {:.2f} TB/s   hot {:6.1f} us = {:.2f} TB/s'.format(tile, cold, nbytes / cold / 1e6, hot, nbytes / hot / 1e6))

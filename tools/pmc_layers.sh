@@ -51,7 +51,7 @@ for (name, which) in sorted(agg):
         line += '  L2 hit %.3f' % (m['TCC_HIT_sum'] / max(1.0, m['TCC_HIT_sum'] + m['TCC_MISS_sum']))
     if 'SQ_WAIT_ANY' in m and 'SQ_WAVE_CYCLES' in m:
         line += '  waves waiting %.2f of their cycles, issuing %.2f' % (m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES'], m.get('SQ_ACTIVE_INST_ANY', 0) / m['SQ_WAVE_CYCLES'])
-    if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'SQ_BUSY_CYCLES' in m:
-        line += '  MFMA busy / SQ busy %.3f' % (m['SQ_VALU_MFMA_BUSY_CYCLES'] / m['SQ_BUSY_CYCLES'])
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'GRBM_GUI_ACTIVE' in m:
+        line += '  MFMA pipe busy %.3f' % (m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024))
     print(line + '   [' + a['_kernel'] + ']')
 PY
