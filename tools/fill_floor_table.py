@@ -81,6 +81,8 @@ for index, (kind, _, desc, name, flops) in enumerate(plan.ops):
     mfma_us = flops / (PEAK * 1e6)
     # compulsory HBM bytes: every input pixel once, the shortcut map, the output map (float32 head outputs: 4 bytes), the weights
     m_in = sum(desc.batch * desc.groups[g].H_in * desc.groups[g].W_in for g in range(desc.n_groups))
+    if desc.KH == 1 and desc.stride == 2:
+        m_in = M                                         # a strided 1x1 layer reads every fourth pixel only
     m_res = sum(desc.batch * desc.groups[g].H_res * desc.groups[g].W_res for g in range(desc.n_groups)) if desc.residual else 0
     hbm_bytes = (m_in * desc.C_in + m_res * desc.C_out) * esz + M * desc.C_out * (4 if desc.out_f32 else esz) + K * desc.C_out * esz
     hbm_us = hbm_bytes / (HBM_TBPS * 1e6)
