@@ -184,7 +184,7 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 // One list for the autotuner below and for gpp_conv2d_tile_candidates (tests draw tiles at random from it).
 static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                              1128128, 1192128, 1128256, 1160256, 1192256, 1224256, 256256, 1256256,
-                             128160, 192160, 1192160, 1128160, 2256256, 1192096, 3256224, 3192160,
+                             128160, 192160, 1192160, 1128160, 2256256, 1192096, 3256224, 3192160, 4128064, 4064064, 4128128, 4064128,
                              128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
 // (the loader-wavefront form of round 2, tile codes 3064128 ..., measured 1.5 - 2x slower on every layer it was built for
 // (profiles/r2/ring_kernel.txt), is no longer part of the library)
@@ -195,7 +195,17 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
     int64_t rows = 0;
     for (int g = 0; g < desc->n_groups; ++g) rows += (int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out;
     const int bn = tile % 1000 ? tile % 1000 : 128;
-    if (tile >= 4000000) return false;
+    if (tile >= 5000000) return false;
+    if (tile >= 4000000) {           // weight-stationary persistent 1 x 1 (x3 types, pre-split maps): the W n-tile and the ring have to fit 160 KB of LDS
+        static const bool no_ws = [] { const char* e = getenv("GPP_NO_WS_TILES"); return e && e[0] == '1'; }();
+        const bool x3_in = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);
+        const int bm = (tile / 1000) % 1000;
+        const gpp_conv_group& G = desc->groups[0];
+        return !no_ws && x3_in && desc->KH == 1 && desc->KW == 1 && desc->stride == 1 && desc->pad_top == 0 && desc->pad_left == 0 && desc->n_groups == 1 &&
+               desc->split_k <= 1 && desc->C_out % bn == 0 && 32 % (desc->C_out / bn) == 0 && G.H_in == G.H_out && G.W_in == G.W_out &&
+               (!desc->residual || ((desc->x3_split & GPP_X3_RES) && G.H_res == G.H_out && G.W_res == G.W_out)) &&
+               (desc->C_in / 32) * bn * 128 + 4 * bm * 128 <= 160 * 1024 && rows >= 256 * 16;
+    }
     static const bool no_mix = [] { const char* e = getenv("GPP_NO_MIX_TILES"); return e && e[0] == '1'; }();      // (A/B of the mixed grids)
     if (tile >= 3000000 && no_mix) return false;
     if (tile >= 3000000) {           // mixed-height grids: x3 types on pre-split inputs, whole 256-column tiles, enough rows for two rounds

@@ -1911,6 +1911,227 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 3 : 2)) void bottleneck_tail_x3_ke
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Weight-stationary, persistent form of the shallow 1 x 1 layers of the x3 types (round 4; tile codes 4000000 + BM * 1000 + BN: 4128064, 4064064,
+// 4128128, 4064128).
+// The 1 x 1 layers of res2 - res4 with 2 - 16 K-steps take their matrix time PLUS their memory time in the tile kernels above: a workgroup's
+// K loop is a chain of dependent tile loads one stage ahead, its epilogue and stores follow, and only two or three such workgroups share a CU
+// (profiles/r4/layer_pmc_f16x3.txt: wavefronts waiting 0.3 - 0.6 of their cycles, traffic = algorithmic).  Here a workgroup of 8 wavefronts
+//   * keeps ONE n-tile of the weights (BN = 64 or 128 output channels x all of K, <= 128 KB) resident in LDS for its whole life,
+//   * walks a sequence of M tiles and streams their activation rows through a ring of R = 4 slabs (one slab = BM rows x one 32-channel
+//     K-step = what a K-step of the tile kernels stages), D = 3 slabs in flight AHEAD of the one computed -- across tile boundaries: the
+//     loads of the next tile's first slabs and of its shortcut rows are in flight while this tile's epilogue runs,
+//   * one s_barrier per K-step as before; waits on the LDS-DMA are COUNTED (vmcnt((D - 1) A_IT): every younger operation is a load, and
+//     loads return in order) except at the first K-step of a tile, where a vmcnt(0) also retires the previous tile's stores (a store
+//     younger than the awaited load would make a counted wait unsafe: loads and stores return out of order with respect to each other).
+// Work split: 256 workgroups = 8 XCDs x 32; the n_tiles = C_out / BN workgroups that share a sequence of M tiles sit on ONE XCD and walk it
+// together, so the activation slabs they all read come from that XCD's L2 once they have been fetched.
+// Every output element is summed in the order of the tile kernels (K-steps ascending; hi * wlo, hi * whi, lo * whi per step; scale, bias,
+// shortcut, ReLU, range, split in the same arithmetic): bit-identical to them (tests/test_conv_f16x3_gpu.py).
+template <int DT, int BM, int BN, bool HASRES>
+__global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const gpp_conv_desc d, const int n_mtiles)
+{
+    static_assert(kX3<DT>, "x3 types on pre-split maps");
+    using xh8 = typename X3Half<DT>::vec;
+    constexpr int NW = 8, WM = 4, WN = 2;
+    constexpr int MF = BM / WM / 16, NF = BN / WN / 16;
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
+    constexpr int NG = NF / 2;                                   // groups of 8 consecutive output channels per lane and row
+    constexpr int R = 4, D = R - 1;
+    constexpr int SLAB = BM * kRowBytes;
+    constexpr bool OSCALE = (DT == GPP_F16X3);
+    static_assert(MF >= 1 && NF % 2 == 0 && A_IT >= 1 && B_IT >= 1 && BN % (8 * NW) == 0, "tile shape: 64 or 128 output channels");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const gpp_conv_group& G = d.groups[0];
+    const int HoWo = G.H_out * G.W_out, Mg = d.batch * HoWo;
+    const int nk = d.C_in / 32;                                  // K-steps (KH = KW = 1)
+    const int n_tiles = d.C_out / BN;                            // divides 32 (checked by the launcher)
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int nt = local % n_tiles, per_xcd = 32 / n_tiles;
+    const int part = xcd * per_xcd + local / n_tiles, P = 8 * per_xcd;
+    const int n0 = nt * BN;
+    const int my_tiles = __builtin_amdgcn_readfirstlane(part < n_mtiles ? (n_mtiles - part + P - 1) / P : 0);
+    if (my_tiles == 0) return;
+    unsigned char* const wbase = smem;                           // nk slabs of BN weight rows, resident
+    unsigned char* const ring = smem + nk * BN * kRowBytes;      // R activation slabs
+
+    const int srow = lane >> 3, gchunk = (lane & 7) ^ srow;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.weight, 0, d.weight_bytes, 0x00020000);
+    {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int w_voff = (n0 + (wave * B_IT + i) * 8 + srow) * d.C_in * 4 + gchunk * 16;
+            for (int ks = 0; ks < nk; ++ks) glds16(w_rsrc, w_voff, ks * kRowBytes, wbase + ks * BN * kRowBytes + (wave * B_IT + i) * 8 * kRowBytes);
+        }
+    }
+    // byte offsets of the activation rows this lane stages for M tile number c of this workgroup's sequence
+    int a_off[A_IT];
+    auto a_offsets = [&](int c) {
+        const int m0 = (part + c * P) * BM;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + (wave * A_IT + i) * 8 + srow;
+            a_off[i] = kOutOfRange;
+            if (m < Mg) {
+                const int b = m / HoWo, p = m - b * HoWo;
+                a_off[i] = (int)((G.in_off + (int64_t)b * G.in_bstride + (int64_t)p * d.in_pitch) * 4) + gchunk * 16;
+            }
+        }
+    };
+    a_offsets(0);
+    int ic = 0, iks = 0, islot = 0;                              // issue cursor: tile, K-step, ring slot
+    auto issue = [&]() {
+        const bool live = ic < my_tiles;                         // past the last slab: a zero-length descriptor (the loads are dropped, the count stays)
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, live ? d.in_bytes : 0, 0x00020000);
+        const int so = __builtin_amdgcn_readfirstlane(iks * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) glds16(ra, a_off[i], so, ring + islot * SLAB + (wave * A_IT + i) * 8 * kRowBytes);
+        islot = (islot + 1) & (R - 1);
+        if (++iks == nk) {
+            iks = 0;
+            ++ic;
+            if (ic < my_tiles) a_offsets(ic);
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < D; ++p) issue();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = ((kk * 4 + fq) ^ (frow & 7)) << 4;
+        a_rd[kk] = (wm * (BM / WM) + frow) * kRowBytes + sw;
+        b_rd[kk] = (wn * (BN / WN) + frow) * kRowBytes + sw;
+    }
+    // scale and bias of this lane's 8 output channels: the same for every tile of the workgroup
+    const int n = n0 + wn * (BN / WN) + fq * 8;                   // group jj: channels n + 32 jj ... + 7
+    float bias_v[NG][8], scale_v[NG][8];
+#pragma unroll
+    for (int jj = 0; jj < NG; ++jj)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bias_v[jj][e] = d.bias ? d.bias[n + 32 * jj + e] : 0.0f;
+            scale_v[jj][e] = (OSCALE && d.out_scale) ? d.out_scale[n + 32 * jj + e] : 1.0f;
+        }
+    // output / shortcut rows of a tile (element offsets), and the shortcut rows' raw [8 hi][8 lo] bits
+    int64_t obase[MF], rbase[MF];
+    bool valid[MF];
+    auto rows_of = [&](int c, int64_t (&ob)[MF], int64_t (&rb)[MF], bool (&ok)[MF]) {
+        const int m0 = (part + c * P) * BM;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + frow;
+            ok[i] = m < Mg;
+            const int mm = ok[i] ? m : 0;                        // (rows past the end: row 0, a valid address that is never stored to)
+            const int b = mm / HoWo, p = mm - b * HoWo;
+            ob[i] = G.out_off + (int64_t)b * G.out_bstride + (int64_t)p * d.out_pitch;
+            rb[i] = G.res_off + (int64_t)b * G.res_bstride + (int64_t)p * d.res_pitch;
+        }
+    };
+    f32x8 rpre[HASRES ? MF : 1][NG];
+    auto fetch_res = [&](const int64_t (&rb)[MF]) {
+        if constexpr (HASRES) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NG; ++jj) {
+                    const char* q = x3_addr(d.residual, rb[i], n + 32 * jj);
+                    rpre[i][jj].lo = *(const f32x4*)q;
+                    rpre[i][jj].hi = *(const f32x4*)(q + 64);
+                }
+        }
+    };
+    rows_of(0, obase, rbase, valid);
+    fetch_res(rbase);
+
+    f32x4 acc[MF][NF];
+    for (int c = 0; c < my_tiles; ++c) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int slot = (c * nk) & (R - 1);
+        for (int ks = 0; ks < nk; ++ks) {
+            // slab (c, ks) has landed: at the first K-step of a tile everything older is retired too (the previous tile's stores: see above)
+            if (ks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * A_IT) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue();                                             // slab (c, ks) + D goes into the slot everyone has just finished reading
+            const unsigned char* sa = ring + slot * SLAB;
+            const unsigned char* sw = wbase + ks * BN * kRowBytes;
+            xh8 ah[MF], al[MF], bh[NF], bl[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                ah[i] = *(const xh8*)(sa + a_rd[0] + i * 16 * kRowBytes);
+                al[i] = *(const xh8*)(sa + a_rd[1] + i * 16 * kRowBytes);
+            }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                bh[j] = *(const xh8*)(sw + b_rd[0] + j * 16 * kRowBytes);
+                bl[j] = *(const xh8*)(sw + b_rd[1] + j * 16 * kRowBytes);
+            }
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    acc[i][j] = X3Half<DT>::mfma(bl[j], ah[i], acc[i][j]);
+                    acc[i][j] = X3Half<DT>::mfma(bh[j], ah[i], acc[i][j]);
+                }
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = X3Half<DT>::mfma(bh[j], al[i], acc[i][j]);
+            slot = (slot + 1) & (R - 1);
+        }
+        // ---- epilogue of tile c; the slabs of the next tiles are in flight underneath it
+        float v[MF][NG][8];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NG; ++jj) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (OSCALE) {
+                        v[i][jj][e] = __builtin_fmaf(acc[i][2 * jj][e], scale_v[jj][e], bias_v[jj][e]);
+                        v[i][jj][4 + e] = __builtin_fmaf(acc[i][2 * jj + 1][e], scale_v[jj][4 + e], bias_v[jj][4 + e]);
+                    } else {
+                        v[i][jj][e] = acc[i][2 * jj][e] + bias_v[jj][e];
+                        v[i][jj][4 + e] = acc[i][2 * jj + 1][e] + bias_v[jj][4 + e];
+                    }
+                }
+                if constexpr (HASRES) {
+                    float r[8];
+                    x3_unpack<DT>(rpre[i][jj].lo, rpre[i][jj].hi, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[i][jj][e] += r[e];
+                }
+            }
+        int64_t ob_next[MF], rb_next[MF];
+        bool ok_next[MF];
+        if (c + 1 < my_tiles) {                                  // the next tile's shortcut rows: requested BEFORE this tile's stores go out
+            rows_of(c + 1, ob_next, rb_next, ok_next);
+            fetch_res(rb_next);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+            if (valid[i]) {
+#pragma unroll
+                for (int jj = 0; jj < NG; ++jj) finish8_pre<DT>(d, v[i][jj], n + 32 * jj, obase[i], false, f32x8());
+            }
+        if (c + 1 < my_tiles) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) { obase[i] = ob_next[i]; rbase[i] = rb_next[i]; valid[i] = ok_next[i]; }
+        }
+    }
+}
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember which devices a kernel has been configured
 // on (one bit per device ordinal; racing first calls both set the same value)
 struct DeviceOnce {
@@ -2060,6 +2281,42 @@ int launch_mix(const gpp_conv_desc& d, hipStream_t st)
     return e == hipSuccess ? GPP_OK : (int)e;
 }
 
+// conv1x1_ws_kernel: which layers it takes, and how it is launched (256 workgroups, W n-tile + ring in LDS).
+template <int DT, int BM, int BN>
+int launch_ws(gpp_conv_desc& d, hipStream_t st)
+{
+    constexpr int R = 4;
+    static_assert(kX3<DT>, "weight-stationary 1 x 1: x3 types");
+    const gpp_conv_group& G = d.groups[0];
+    if (!(d.x3_split & GPP_X3_IN) || d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad_top != 0 || d.pad_left != 0 || d.n_groups != 1 || d.split_k > 1)
+        return GPP_ERR_UNSUPPORTED;
+    if (d.C_out % BN != 0 || 32 % (d.C_out / BN) != 0 || d.C_in % 32 != 0) return GPP_ERR_UNSUPPORTED;
+    if (G.H_in != G.H_out || G.W_in != G.W_out) return GPP_ERR_UNSUPPORTED;
+    if (d.residual && (!(d.x3_split & GPP_X3_RES) || G.H_res != G.H_out || G.W_res != G.W_out)) return GPP_ERR_UNSUPPORTED;   // shortcut: pre-split, same size
+    const int nk = d.C_in / 32;
+    const int lds = nk * BN * kRowBytes + R * BM * kRowBytes;
+    if (lds > 160 * 1024) return GPP_ERR_UNSUPPORTED;
+    const int tiles = prepare<BM, BN>(d);                       // buffer extents (+ the weight-row check)
+    if (tiles < 0) return tiles;
+    const int n_mtiles = (int)(((int64_t)d.batch * G.H_out * G.W_out + BM - 1) / BM);
+    int rc;
+    if (d.residual) {
+        static DeviceOnce once;
+        auto kernel = conv1x1_ws_kernel<DT, BM, BN, true>;
+        rc = once.configure(kernel, 160 * 1024);
+        if (rc != GPP_OK) return rc;
+        kernel<<<dim3(256), dim3(512), lds, st>>>(d, n_mtiles);
+    } else {
+        static DeviceOnce once;
+        auto kernel = conv1x1_ws_kernel<DT, BM, BN, false>;
+        rc = once.configure(kernel, 160 * 1024);
+        if (rc != GPP_OK) return rc;
+        kernel<<<dim3(256), dim3(512), lds, st>>>(d, n_mtiles);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}
+
 template <int DT>
 int dispatch(gpp_conv_desc& d, hipStream_t st)
 {
@@ -2135,6 +2392,10 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                             case 2256256: return launch_dual<DT>(d, st);      // C_out = 256 k + 128: the dual-shape grid
                             case 3256224: return launch_mix<DT, 256, 224>(d, st);       // 3000000 + BMA * 1000 + BMB: two tile heights, one grid
                             case 3192160: return launch_mix<DT, 192, 160>(d, st);
+                            case 4128064: return launch_ws<DT, 128, 64>(d, st);        // 4000000 + BM * 1000 + BN: weight-stationary persistent 1 x 1
+                            case 4064064: return launch_ws<DT, 64, 64>(d, st);
+                            case 4128128: return launch_ws<DT, 128, 128>(d, st);
+                            case 4064128: return launch_ws<DT, 64, 128>(d, st);
                             default: break;
                         }
                     }
@@ -2144,7 +2405,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                 }
                 switch (d.tile_hint) {
                     case 256: case 1128128: case 1192128: case 1128256: case 1192256: case 1192160: case 1128160: case 2256256: case 512: case 256256: case 1256256:
-                    case 192256: case 128256: case 1192096: case 3256224: case 3192160: case 1224256: case 1160256:
+                    case 192256: case 128256: case 1192096: case 3256224: case 3192160: case 1224256: case 1160256: case 4128064: case 4064064: case 4128128: case 4064128:
                         return GPP_ERR_UNSUPPORTED;
                     default: return GPP_ERR_BAD_ARG;
                 }

@@ -160,7 +160,10 @@ typedef struct gpp_conv_desc {
                                        1128256, 1160256, 1192256, 1224256, 1256256, 1128160, 1192096 and 2256256; 192160 exists on pre-split inputs only;
                                        3256224 / 3192160 (3000000 + BMA * 1000 + BMB, C_out % 256 == 0, pre-split inputs): 256-column tiles
                                        of two heights in ONE grid -- whole rounds of BMA-row tiles, the rest in BMB-row tiles -- against the
-                                       round quantisation of one-workgroup-per-CU tiles (GPP_ERR_UNSUPPORTED where it gains nothing).
+                                       round quantisation of one-workgroup-per-CU tiles (GPP_ERR_UNSUPPORTED where it gains nothing);
+                                       4128064 / 4064064 / 4128128 / 4064128 (4000000 + BM * 1000 + BN; 1 x 1, stride 1, one map, pre-split input / shortcut,
+                                       C_out a multiple of BN with 32 % (C_out / BN) == 0, K small enough for BN x K weights + the activation ring in 160 KB of LDS): the
+                                       weight-stationary persistent form of the shallow 1 x 1 layers.
                                        gpp_conv2d_tile_candidates lists what a given layer accepts; see gpp_conv2d_autotune */
     int32_t reserved;               /* must be 0 (anything else: GPP_ERR_BAD_ARG).  Only the diagnostic -DGPP_STAMPS build of the
                                        library (make stamps; tools/bench_conv.py) reads it: bit 0 skip the tile loads, bit 1 skip

@@ -473,3 +473,83 @@ def test_f16x3_range_ledger_counts_what_the_half_range_alters_and_keeps_non_fini
         bias.copy_(saved)
         hip.check(lib.gpp_x3_range_events(ctypes.byref(n), 0))
         assert n.value == 0                                                    # reset
+
+
+WS_CASES = [  # B, H, W, C_in, C_out, shortcut, relu, float32 output
+    (2, 37, 41, 256, 64, False, True, False),        # one n-tile: every workgroup its own M tiles
+    (2, 29, 23, 128, 512, True, True, False),        # 8 n-tiles share an M sequence on one XCD; shortcut
+    (3, 13, 17, 256, 1024, True, True, False),       # 16 n-tiles
+    (2, 19, 21, 512, 128, False, True, False),       # K = 512: 128 KB of weights, only the 64-row form fits
+    (1, 9, 7, 64, 256, False, False, False),         # two K-steps: fewer than the ring runs ahead
+    (2, 13, 42, 512, 2048, True, True, False),       # 32 n-tiles
+    (1, 5, 3, 128, 64, True, False, False),          # 15 rows: one ragged tile, 255 workgroups with nothing to do
+    (2, 23, 31, 128, 192, False, False, True),       # float32 output (a head-like layer); 192 / 64 = 3 n-tiles do not divide 32: refused
+    (2, 23, 31, 128, 128, False, False, True),       # float32 output, accepted
+    (4, 101, 167, 256, 64, False, True, False),      # res2-like: 67 468 rows, 528 M tiles over 256 workgroups
+]
+
+
+@pytest.mark.parametrize('dtype', ['f16x3', 'bf16x3'])
+@pytest.mark.parametrize('case', WS_CASES, ids=['{}x{}x{}_{}to{}{}{}{}'.format(c[0], c[1], c[2], c[3], c[4], '_sc' if c[5] else '', '_relu' if c[6] else '', '_f32' if c[7] else '') for c in WS_CASES])
+def test_weight_stationary_1x1_gives_the_bits_of_the_tile_kernels(case, dtype):
+    """ tile codes 4128064 / 4064064 / 4128128 / 4064128 (conv1x1_ws_kernel): the W n-tile resident in LDS, activation slabs streamed through a ring across
+    tile boundaries, counted waits -- against the plain 128 x 128 tile on the same pre-split maps, bit for bit; layers it does not
+    take (weights + ring beyond 160 KB, n-tile counts that do not divide 32) are refused, not approximated """
+    B, H, W, cin, cout, res, relu, f32out = case
+    g = torch.Generator().manual_seed(B * H * W + cin + cout)
+    dev = torch.device('cuda')
+    k = torch.randn((1, 1, cin, cout), generator=g) * (2.0 / cin) ** 0.5
+    k = k * torch.pow(2.0, torch.randint(-3, 4, (cout,), generator=g).float())[None, None, None, :]
+    w = C.pack_weight(k.numpy(), dtype, dev)
+    sc = C.out_scale_of(k.numpy(), dev) if dtype == 'f16x3' else None
+    bias = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    xin = C.FMap.empty(B, H, W, cin, torch.float32, dev, split=True, half=dtype)
+    xin.write(torch.randn((B, H, W, cin), generator=g))
+    rmap = None
+    if res:
+        rm = C.FMap.empty(B, H, W, cout, torch.float32, dev, split=True, half=dtype)
+        rm.write(torch.randn((B, H, W, cout), generator=g))
+        rmap = [rm]
+
+    def run(tile):
+        out = C.FMap.empty(B, H, W, cout, torch.float32, dev, split=not f32out, half=dtype)
+        out.buf.fill_(float('nan'))
+        d = C.conv_desc([xin], [out], w, bias, 1, 1, cin, cout, relu=relu, residuals=rmap, dtype=dtype, tile_hint=tile, out_scale=sc, out_f32=f32out)
+        rc = hip.lib().gpp_conv2d_igemm(ctypes.byref(d), hip.stream_ptr())
+        torch.cuda.synchronize()
+        return rc, out.buf.view(torch.int32).cpu()
+    rc, base = run(128128)
+    assert rc == 0
+    for tile in (4128064, 4064064, 4128128, 4064128):
+        bm, bn = (tile // 1000) % 1000, tile % 1000
+        fits = (cin // 32) * bn * 128 + 4 * bm * 128 <= 160 * 1024
+        divides = cout % bn == 0 and 32 % (cout // bn) == 0
+        rc, got = run(tile)
+        if fits and divides:
+            assert rc == 0, (tile, rc)
+            assert torch.equal(got, base), (tile, int((got != base).sum()))
+        else:
+            assert rc == -4, (tile, rc)                        # GPP_ERR_UNSUPPORTED
+
+
+def test_weight_stationary_1x1_is_offered_where_it_applies():
+    """ gpp_conv2d_tile_candidates lists the weight-stationary forms for a shallow 1 x 1 layer on pre-split maps, and for nothing else """
+    dev = torch.device('cuda')
+
+    def cands(cin, cout, ksz, split, stride=1):
+        k = torch.randn((ksz, ksz, cin, cout)) * 0.05
+        w = C.pack_weight(k.numpy(), 'f16x3', dev)
+        x = C.FMap.empty(8, 51, 167, cin, torch.float32, dev, split=split, half='f16x3')
+        o = C.FMap.empty(8, 51 if stride == 1 else 26, 167 if stride == 1 else 84, cout, torch.float32, dev, split=split, half='f16x3')
+        d = C.conv_desc([x], [o], w, torch.zeros((cout,), device=dev), ksz, ksz, cin, cout, pad=(ksz // 2, ksz // 2), stride=stride, dtype='f16x3',
+                        out_scale=C.out_scale_of(k.numpy(), dev))
+        tiles, count = (ctypes.c_int * 64)(), ctypes.c_int(0)
+        hip.check(hip.lib().gpp_conv2d_tile_candidates(ctypes.byref(d), tiles, 64, ctypes.byref(count)), 'candidates')
+        return set(tiles[:count.value])
+    assert {4128064, 4064064, 4128128, 4064128} <= cands(128, 512, 1, True)
+    assert 4064064 in cands(512, 128, 1, True) and 4128064 not in cands(512, 128, 1, True)      # 128 KB of weights: the 64-row ring only
+    ws = {4128064, 4064064, 4128128, 4064128}
+    assert not (ws & cands(128, 512, 1, False))                                 # float32 maps
+    assert not (ws & cands(128, 128, 3, True))                                  # 3 x 3
+    assert not (ws & cands(1024, 256, 1, True))                                 # 256 KB of weights
+    assert not (ws & cands(256, 128, 1, True, stride=2))                        # strided
