@@ -13,6 +13,9 @@ def short(k):
     m = re.search(r'conv_igemm_mix_kernel<(\d+), (\d+), (\d+)', k)
     if m:
         return 'igemm mix {}+{}'.format(m.group(2), m.group(3))
+    m = re.search(r'conv1x1_ws_kernel<(\d+), (\d+), (\d+)', k)
+    if m:
+        return 'ws 1x1 {}x{}'.format(m.group(2), m.group(3))
     for key in ('conv_igemm_dual', 'bottleneck_tail_x3', 'bottleneck_tail', 'stem_pool_mfma', 'stem_mfma_x3', 'stem_mfma', 'maxpool', 'relu', 'splitk_reduce',
                 'clear_counters', 'candidates', 'nms', 'emit_kernel', 'canonical_planes', 'poll'):
         if key in k:

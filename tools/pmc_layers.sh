@@ -18,7 +18,7 @@ out = sys.argv[1]
 # the named ops are the LAST launches of the process: 1 + 8 + 4 = 13 launches per op, in the order given
 per_pass = {}
 for f in glob.glob(out + '/*/**/*counter_collection.csv', recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if 'conv_igemm' in r['Kernel_Name'] or 'bottleneck_tail' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(f)) if any(k in r['Kernel_Name'] for k in ('conv_igemm', 'bottleneck_tail', 'conv1x1_ws'))]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     by_disp = collections.OrderedDict()
     for r in rows:
@@ -38,7 +38,8 @@ for f, disp in per_pass.items():
             for c, v in d.items():
                 if not c.startswith('_'):
                     agg[(name, which)][c].append(v)
-            agg[(name, which)]['_kernel'] = re.sub(r'\(.*', '', d['_k'])[-70:]
+            m_ = re.search(r'(conv_igemm\w*<[^>]*>|bottleneck_tail\w*<[^>]*>|conv1x1_ws_kernel<[^>]*>)', d['_k'])
+            agg[(name, which)]['_kernel'] = (m_.group(1) if m_ else d['_k'][:60]) + ' grid ' + d['_g']
 for (name, which) in sorted(agg):
     a = agg[(name, which)]
     m = {c: sum(v) / len(v) for c, v in a.items() if not c.startswith('_')}
@@ -53,5 +54,7 @@ for (name, which) in sorted(agg):
         line += '  waves waiting %.2f of their cycles, issuing %.2f' % (m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES'], m.get('SQ_ACTIVE_INST_ANY', 0) / m['SQ_WAVE_CYCLES'])
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'GRBM_GUI_ACTIVE' in m:
         line += '  MFMA pipe busy %.3f' % (m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024))
+    if 'SQ_INSTS_VALU' in m and 'SQ_INSTS_MFMA' in m:
+        line += '  non-MFMA VALU per MFMA %.2f' % (m['SQ_INSTS_VALU'] / m['SQ_INSTS_MFMA'] - 1.0)
     print(line + '   [' + a['_kernel'] + ']')
 PY

@@ -29,6 +29,12 @@ def short(k):
         return 'fused tail %sx%s' % (m.group(2), m.group(3))
     if 'conv_igemm_dual_kernel' in k:
         return 'igemm 256x256 + 512x128 (dual grid)'
+    m = re.search(r'conv_igemm_mix_kernel<(\d+), (\d+), (\d+)', k)
+    if m:
+        return 'igemm %sx256 + %sx256 (mixed heights)' % (m.group(2), m.group(3))
+    m = re.search(r'conv1x1_ws_kernel<(\d+), (\d+), (\d+)', k)
+    if m:
+        return 'ws 1x1 %sx%s (weights resident)' % (m.group(2), m.group(3))
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?>', k)
     if m:
         return 'igemm %sx%s w%sx%s%s%s' % (m.group(2), m.group(3), m.group(4), m.group(5), ' pipe' if m.group(7) in ('true', '1') else '',
@@ -59,7 +65,7 @@ def main(path, backbone='resnet50', fused='0,1'):
         k = r['Kernel_Name']
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         total += d
-        if 'conv_igemm' in k or 'bottleneck_tail' in k:
+        if 'conv_igemm' in k or 'bottleneck_tail' in k or 'conv1x1_ws' in k:
             name = names[ci] if ci < len(names) else '?'
             ci += 1
         elif 'splitk_reduce' in k:
