@@ -206,8 +206,6 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
                (!desc->residual || ((desc->x3_split & GPP_X3_RES) && G.H_res == G.H_out && G.W_res == G.W_out)) &&
                (desc->C_in / 32) * bn * 128 + 4 * bm * 128 <= 160 * 1024 && rows >= 256 * 16;
     }
-    static const bool r3_only = [] { const char* e = getenv("GPP_R3_TILES"); return e && e[0] == '1'; }();       // (A/B: only the tile set of round 3)
-    if (r3_only && (tile >= 3000000 || tile == 1160256 || tile == 1224256 || (tile && bn == 64 && desc->C_out > 256))) return false;
     static const bool no_mix = [] { const char* e = getenv("GPP_NO_MIX_TILES"); return e && e[0] == '1'; }();      // (A/B of the mixed grids)
     if (tile >= 3000000 && no_mix) return false;
     if (tile >= 3000000) {           // mixed-height grids: x3 types on pre-split inputs, whole 256-column tiles, enough rows for two rounds
