@@ -701,7 +701,11 @@ class RetinaNet3D(object):
             if key in self._tuned and not self._tile_is_listed(desc, self._tuned[key][0]):
                 del self._tuned[key]                 # a remembered tile this build does not offer for this layer: time the layer again
             if key not in self._tuned:
-                iters = (2 if self.esz == 4 else 4) if flops > 5e10 else (4 if self.esz == 4 else 16)
+                # launches per candidate and repetition (the library times two repetitions and keeps the faster).  The float32 path's launches are
+                # 3 x as long as the x3 types': fewer of them.  Round 4: the x3 types used the float32 counts (2 / 4) -- a big layer's choice then rested
+                # on four launches per candidate, and one tuning run in ~60 picked a tile that cost the whole run 5 %
+                slow = self.dtype == 'f32'
+                iters = (2 if slow else 6) if flops > 5e10 else (4 if slow else 16)
                 hip.check(hip.lib().gpp_conv2d_autotune(ctypes.byref(desc), iters, hip.stream_ptr(), ctypes.byref(best)),
                           'gpp_conv2d_autotune')
                 self._tuned[key] = (int(desc.tile_hint), round(float(best.value), 2))
