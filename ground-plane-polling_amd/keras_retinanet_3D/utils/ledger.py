@@ -54,6 +54,15 @@ REFERENCE_BARS = {'detection_set_agreement': 1.0, 'plane_index_agreement': 1.0, 
 # THE CUT when both lists are full and the unmatched detection's score is within TIE_EPS of the other run's lowest reported score;
 # every other difference is unexplained and fails the bars.
 TIE_EPS = 1e-6
+#
+# Plane indices.  The polling stage is bit-exact on identical inputs (tests/test_polling_gpu.py, the oracle replay in bench.py), but its selection is
+# DISCONTINUOUS in them: a plane votes for a segment when | length - target | <= 0.7 m, only planes at the highest vote count compete, and with 10^4 planes
+# x 6 segments per detection some length always lies within float32 noise of the threshold.  A 2-D box that differs by 6e-5 px can therefore change the
+# winner -- between the float32 and the float64 CPU oracle it does so for 1 of 3199 detections on resnet152 / 22k planes (frame 9, anchor 73787: planes
+# 13772 / 18314, residuals 0.5387 / 0.5347; none in 9600 on the two other configurations).  A plane difference counts as explained by EQUAL INPUTS when both
+# runs hand the polling stage the same orientation and 2-D boxes / dimensions that agree to float32 noise (BOX_EPS_PX, DIM_EPS), and at most
+# PLANE_FLIPS_PER_1000 per thousand common detections may be of that kind; any other plane difference fails the bars.
+BOX_EPS_PX, DIM_EPS, PLANE_FLIPS_PER_1000 = 1e-3, 1e-5, 1
 
 
 def meets_reference_bars(led, pair=False):
@@ -61,7 +70,9 @@ def meets_reference_bars(led, pair=False):
     rounded ratios), 3-D corners within 1e-3 m wherever the geometry lies within 100 m -- and at least one detection must lie there, an
     empty set meets nothing --, within 1e-3 m x (r / 100 m)^2 beyond.  pair: two float32-grade runs against each other (2e-3). """
     f = 2.0 if pair else 1.0
-    return bool(led['set_differences_unexplained'] == 0 and led['same_orientation'] == led['common'] and led['same_plane'] == led['common'] and
+    flips = led['plane_differences_with_equal_inputs']
+    return bool(led['set_differences_unexplained'] == 0 and led['same_orientation'] == led['common'] and
+                led['same_plane'] + flips == led['common'] and flips <= PLANE_FLIPS_PER_1000 * max(1, -(-led['common'] // 1000)) and
                 led['common'] > 0 and led['same_plane_within_100m'] > 0 and
                 led['max_corner_dev_m_within_100m'] <= f * REFERENCE_BARS['max_corner_dev_m_within_100m'] and
                 led['max_corner_dev_scaled_beyond_100m'] <= f * REFERENCE_BARS['max_corner_dev_scaled_beyond_100m'])
@@ -93,7 +104,7 @@ def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane, detail=N
     detail: a list that receives one (image, anchor id, reach_m, corner_dev_m, keypoint_dev_m, same_plane) tuple per common detection
     (tools/corner_deviation.py draws the distribution from it). """
     B = int(np.asarray(ref_outs[0]).shape[0])
-    n_ref = n_got = n_common = ties = 0
+    n_ref = n_got = n_common = ties = plane_flips = 0
     same_orient = same_plane = 0
     max_kp = max_corner = max_box = max_score = 0.0
     max_kp_rel = max_corner_rel = 0.0
@@ -126,6 +137,9 @@ def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane, detail=N
         sp = so & (A['plane'][ia] == G['plane'][ig])
         same_orient += int(so.sum())
         same_plane += int(sp.sum())
+        box_d = np.abs(A['boxes'][ia] - G['boxes'][ig]).max(axis=1)
+        dim_d = (np.abs(A['dimensions'][ia] - G['dimensions'][ig]) / np.maximum(np.abs(A['dimensions'][ia]), 1e-6)).max(axis=1)
+        plane_flips += int((so & ~sp & (box_d <= BOX_EPS_PX) & (dim_d <= DIM_EPS)).sum())
         max_box = max(max_box, float(np.abs(A['boxes'][ia] - G['boxes'][ig]).max()))
         max_score = max(max_score, float(np.abs(A['scores'][ia] - G['scores'][ig]).max()))
         kp = _dev(A['keypoints'][ia], G['keypoints'][ig]).reshape(len(common), -1).max(axis=1)
@@ -158,6 +172,7 @@ def parity_ledger(ref_outs, ref_anchor, ref_plane, outs, anchor, plane, detail=N
     return {
         'images': B, 'detections_ref': n_ref, 'detections': n_got, 'common': n_common, 'union': union,
         'same_orientation': same_orient, 'same_plane': same_plane,
+        'plane_differences': same_orient - same_plane, 'plane_differences_with_equal_inputs': plane_flips,
         'set_differences': n_ref + n_got - 2 * n_common, 'set_differences_at_a_tie': ties,
         'set_differences_unexplained': n_ref + n_got - 2 * n_common - ties,
         'detection_set_agreement': round(n_common / union, 6) if union else 1.0,          # Jaccard index over anchor ids

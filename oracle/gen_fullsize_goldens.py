@@ -6,8 +6,8 @@ What the CPU oracle returns for whole 402x1333 frames -- conv stack (oracle/net_
 (oracle/decode_np.py), polling (oracle/polling.c) -- for every backbone / plane database BASELINE.json's configs name:
 
     resnet50  + 1k  planes   frames 0..63   (frames 0..7 = rank 0's batch 0 of bench.py)     configs[1], configs[2]
-    resnet101 + 10k planes   frames 0..7                                                    configs[3]
-    resnet152 + 22k planes   frames 0..7    (config 5's per-GPU share is the first 4)        configs[4]
+    resnet101 + 10k planes   frames 0..31   (config 4's batch is the first 8)                configs[3]
+    resnet152 + 22k planes   frames 0..31   (config 5's per-GPU share is the first 4)        configs[4]
 
 each in TWO precisions of the conv stack:
     f32   float32 throughout, literal BatchNormalization: the reference's floatx graph (models/retinanet.py:395-422)
@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'ground-plane-polling_amd'))
 sys.path.insert(0, ROOT)
 
-CONFIGS = [('resnet50', '1k', 64), ('resnet101', '10k', 8), ('resnet152', '22k', 8)]
+CONFIGS = [('resnet50', '1k', 64), ('resnet101', '10k', 32), ('resnet152', '22k', 32)]
 H, W = 402, 1333
 
 

@@ -3,16 +3,16 @@ The HIP path against the CPU ORACLE at the BASELINE sizes, for every backbone / 
 reference-precision type (f32) and in the headline type (f16x3):
 
     resnet50  + 1k  planes, 64 frames (8 batches of 8)     configs[1] / [2]
-    resnet101 + 10k planes,  8 frames (batch 8)             configs[3]
-    resnet152 + 22k planes,  8 frames (2 batches of 4)      configs[4]'s per-GPU share
+    resnet101 + 10k planes, 32 frames (4 batches of 8)      configs[3]
+    resnet152 + 22k planes, 32 frames (8 batches of 4)      configs[4]'s per-GPU share
 
 The oracle's side is DATA: tests/golden/fullsize_<backbone>_<db>_{f32,f64}.npz hold what oracle/net_torch.py + decode_np.py + polling.c
 return for those frames (oracle/gen_fullsize_goldens.py; 0.5 TFLOP per frame and precision: minutes of host time, too slow to repeat in
 every GPU run).  f64 = the conv stack in float64 = the exact value of what the reference's float32 graph computes; f32 = one float32
 CPU evaluation of it.  What is asserted (utils/ledger.py has the reasoning and the measured numbers behind every bar):
 
-  * against the f64 oracle: the same detections up to ties at the top-k cut, the same orientation and plane index for EVERY common
-    detection, 3-D corners within 1e-3 m inside 100 m and within 1e-3 m x (r / 100 m)^2 beyond -- ledger.REFERENCE_BARS, for f16x3;
+  * against the f64 oracle: the same detections up to ties at the top-k cut, the same orientation for EVERY common detection, the same
+    plane index for every one but at most 1 per 1000 whose polling inputs agree to float32 noise (a vote at its threshold), 3-D corners within 1e-3 m inside 100 m and within 1e-3 m x (r / 100 m)^2 beyond -- ledger.REFERENCE_BARS, for f16x3;
     the float32 HIP path is held to 1.5e-3: float32 itself is that far from the exact value (the float32 CPU oracle: 1.15e-3)
   * "as good as float32": the p50 / p90 / p99 of f16x3's corner deviation from f64 are no larger than 1.25 x those of the float32
     CPU oracle from f64 (computed from the two fixtures)
@@ -35,7 +35,7 @@ import corner_deviation as CD  # noqa: E402  (tools/corner_deviation.py: fixture
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = {'resnet50_1k': (64, 8), 'resnet101_10k': (8, 8), 'resnet152_22k': (8, 4)}        # frames, batch
+CONFIGS = {'resnet50_1k': (64, 8), 'resnet101_10k': (32, 8), 'resnet152_22k': (32, 4)}      # frames, batch
 
 
 def run_hip(config, dtype):
@@ -77,8 +77,15 @@ def test_hip_path_against_the_cpu_oracle_fixtures(config, dtype):
     assert exact['set_differences_unexplained'] == 0 and exact['set_differences'] <= 2 * CONFIGS[config][0] // 4, exact
     for s in CD.set_differences(g64, got, g64[3]):
         assert s['gap_at_the_cut'] <= ledger.TIE_EPS, s
-    # the same orientation and the same plane for every detection both report
-    assert exact['same_orientation'] == exact['common'] and exact['same_plane'] == exact['common'], exact
+    # the same orientation for every detection both report, and the same plane -- up to ledger.PLANE_FLIPS_PER_1000 detections whose polling
+    # INPUTS agree to float32 noise (<= 1e-3 px) and whose plane still differs: a vote at its 0.7 m threshold (ledger.py; the float32 CPU
+    # oracle has one such detection in 3199 against the f64 one on resnet152 / 22k planes, asserted below so that the allowance stays honest)
+    flips = exact['plane_differences_with_equal_inputs']
+    print('    plane differences: {} (with equal inputs {}); float32 CPU oracle vs f64: {}'.format(
+        exact['plane_differences'], flips, floor['plane_differences']))
+    assert exact['same_orientation'] == exact['common'] and exact['same_plane'] + flips == exact['common'], exact
+    assert flips <= ledger.PLANE_FLIPS_PER_1000 * -(-exact['common'] // 1000), exact
+    assert floor['plane_differences'] == floor['plane_differences_with_equal_inputs'] == (1 if config == 'resnet152_22k' else 0)
     # 3-D corners
     bar = 1.0e-3 if dtype == 'f16x3' else 1.5e-3
     assert exact['same_plane_within_100m'] >= 0.8 * exact['common']

@@ -130,3 +130,23 @@ def test_pair_bars_are_twice_the_metre_bars():
     assert 1.2e-3 < led['max_keypoint_dev_m_within_100m'] < 1.8e-3
     if led['max_corner_dev_m_within_100m'] <= 2e-3:
         assert not ledger.meets_reference_bars(led) and ledger.meets_reference_bars(led, pair=True)
+
+
+def test_a_plane_difference_with_equal_polling_inputs_is_told_from_one_with_different_inputs():
+    """ the polling selection is discontinuous in its inputs (a vote at its 0.7 m threshold): with boxes / dimensions that agree to float32
+    noise one flip per thousand detections is within the bars; a flip whose boxes differ visibly, or more flips than that, is not """
+    o, a, p = fake_run(batch=10, valid=100)
+    o2 = [x.copy() for x in o]
+    p2 = p.copy()
+    p2[0, 7] += 1
+    o2[0][0, 7] += np.float32(6e-5)                                      # the 2-D box moved by float32 noise
+    led = ledger.parity_ledger(o, a, p, o2, a, p2)
+    assert led['plane_differences'] == led['plane_differences_with_equal_inputs'] == 1 and led['same_plane'] == 999
+    assert ledger.meets_reference_bars(led)
+    p2[3, 1] += 1                                                        # a second one in 1000: over the allowance
+    led = ledger.parity_ledger(o, a, p, o2, a, p2)
+    assert led['plane_differences_with_equal_inputs'] == 2 and not ledger.meets_reference_bars(led)
+    p2[3, 1] -= 1
+    o2[0][0, 7] += np.float32(0.01)                                      # the box moved by 0.01 px: a difference of the inputs, not a vote at its threshold
+    led = ledger.parity_ledger(o, a, p, o2, a, p2)
+    assert led['plane_differences'] == 1 and led['plane_differences_with_equal_inputs'] == 0 and not ledger.meets_reference_bars(led)

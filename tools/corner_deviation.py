@@ -2,7 +2,7 @@
 """
 Distribution of the end-to-end deviation of the HIP path from the CPU oracle at the BASELINE sizes, over the frames of the committed
 full-size fixtures (tests/golden/fullsize_*.npz, made by oracle/gen_fullsize_goldens.py): not a maximum over 8 frames, the whole
-distribution over 64 (resnet50, 1k planes) / 8 (resnet101, 10k; resnet152, 22k).
+distribution over 64 (resnet50, 1k planes) / 32 (resnet101, 10k) / 32 (resnet152, 22k) frames.
 
 For every arithmetic mode asked for (default f32 and f16x3) and each of the two oracle precisions
 
@@ -65,6 +65,8 @@ def compare(ref, got, ledger):
     detail = []
     led = ledger.parity_ledger(ref[0], ref[1], ref[2], got[0], got[1], got[2], detail=detail)
     led['distribution'] = distribution(detail)
+    led['plane_difference_list'] = [{'frame': int(i), 'anchor': int(a), 'planes': [int(ref[2][i][list(ref[1][i]).index(a)]), int(got[2][i][list(got[1][i]).index(a)])]}
+                                    for i, a, _, _, _, s in detail if not s]
     led['meets_reference_bars'] = ledger.meets_reference_bars(led)
     return led
 
@@ -121,7 +123,7 @@ def main():
         got = ([np.concatenate([o[k] for o in outs]) for k in range(8)], np.concatenate(aidx), np.concatenate(pidx))
         for name, ref in (('f64 oracle', g64), ('f32 CPU oracle', g32)):
             row = compare(ref, got, ledger)
-            row['set_differences'] = set_differences(ref, got, ref[3])
+            row['set_difference_list'] = set_differences(ref, got, ref[3])
             report['rows']['{} HIP vs {}'.format(dtype, name)] = row
         if dtype == 'f16x3':
             report['f16x3_range_events'] = model.x3_range_events()
@@ -139,8 +141,10 @@ def main():
                                           r['meets_reference_bars'])))
         for k, v in d.get('by_distance', {}).items():
             print('      {:>8s}: n {:5d}  p50 {:.2e}  max {:.2e}'.format(k, v['n'], v['p50'], v['max']))
-        for s in r.get('set_differences', []):
+        for s in r.get('set_difference_list', []):
             print('      set difference:', s)
+        for s in r.get('plane_difference_list', []):
+            print('      plane difference ({} of {} with equal polling inputs):'.format(r['plane_differences_with_equal_inputs'], r['plane_differences']), s)
     if 'f16x3_range_events' in report:
         print('f16x3 range events (values outside the half range stored by an epilogue):', report['f16x3_range_events'])
     if args.json:
