@@ -150,6 +150,16 @@ constexpr bool kSpreadDma = GPP_DMA_SPREAD != 0;
 // Diagnostic build only (-DGPP_STAMPS, tools/bench_conv.py stamps): wave 0 of every workgroup writes the 100 MHz
 // real-time counter at five points into a buffer of its own (handed in through the otherwise unused zero_page
 // field when reserved bit 4 is set).  No output depends on it; the production build contains none of this.
+// Order of the matrix instructions inside a fragment row: serpentine (even rows left to right, odd rows right to left), so that two consecutive
+// MFMAs always share one operand.  The matrix pipe's clock under load depends on what toggles between instructions: on post-ReLU data a
+// register-only x3 loop sustains 2075 TFLOP/s in this order against 1969 with both row ends changing (tools/micro/mfma_order.hip,
+// profiles/r4/mfma_order.txt).  Per accumulator the three terms keep their order: the bytes do not change.
+#ifndef GPP_X3_SERPENTINE
+#define GPP_X3_SERPENTINE 2
+#endif
+#define GPP_SERP(g, j, n) ((GPP_X3_SERPENTINE && ((g) & 1)) ? (n) - 1 - (j) : (j))
+#define GPP_SERP2(g, j, n) ((GPP_X3_SERPENTINE > 1 && ((g) & 1)) ? (n) - 1 - (j) : (j))      // the loops the compiler schedules itself
+
 #ifdef GPP_STAMPS
 #define GPP_STAMP(k)                                                                                          \
     do {                                                                                                      \
@@ -853,7 +863,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
 #pragma unroll
                     for (int j = BJ0(g); j < BJ0(g + 1); ++j) GPP_ABL(abl_rdab) bh[j] = *(const xh8*)(scur + b_rd[0] + j * 16 * kRowBytes);
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bl[j], ah[g], acc[g][j]);
+                    for (int j = 0; j < NF; ++j) { const int js = GPP_SERP(g, j, NF); acc[g][js] = X3Half<DT>::mfma(bl[js], ah[g], acc[g][js]); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #ifdef GPP_STAMPS
@@ -868,7 +878,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                     }
                     GPP_ABL(abl_rdab) al[g] = *(const xh8*)(scur + a_rd[1] + g * 16 * kRowBytes);
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bh[j], ah[g], acc[g][j]);
+                    for (int j = 0; j < NF; ++j) { const int js = GPP_SERP(g, j, NF); acc[g][js] = X3Half<DT>::mfma(bh[js], ah[g], acc[g][js]); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #ifdef GPP_STAMPS
@@ -916,7 +926,7 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                     }
 #endif
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[g][j] = X3Half<DT>::mfma(bh[j], al[g], acc[g][j]);
+                    for (int j = 0; j < NF; ++j) { const int js = GPP_SERP(g, j, NF); acc[g][js] = X3Half<DT>::mfma(bh[js], al[g], acc[g][js]); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #if !GPP_X3_TAP_EARLY
@@ -1074,13 +1084,14 @@ __device__ __forceinline__ void conv_igemm_body(const gpp_conv_desc& d, const in
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
                     for (int j = 0; j < NF; ++j) {
-                        acc[i][j] = X3Half<DT>::mfma(bl[j], ah[i], acc[i][j]);
-                        acc[i][j] = X3Half<DT>::mfma(bh[j], ah[i], acc[i][j]);
+                        const int js = GPP_SERP2(i, j, NF);
+                        acc[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc[i][js]);
+                        acc[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc[i][js]);
                     }
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) acc[i][j] = X3Half<DT>::mfma(bh[j], al[i], acc[i][j]);
+                    for (int j = 0; j < NF; ++j) { const int js = GPP_SERP2(i, j, NF); acc[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc[i][js]); }
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -1767,13 +1778,14 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 3 : 2)) void bottleneck_tail_x3_ke
         for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int j = 0; j < NF1; ++j) {
-                acc1[i][j] = X3Half<DT>::mfma(bl[j], ah[i], acc1[i][j]);
-                acc1[i][j] = X3Half<DT>::mfma(bh[j], ah[i], acc1[i][j]);
+                const int js = GPP_SERP2(i, j, NF1);
+                acc1[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc1[i][js]);
+                acc1[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc1[i][js]);
             }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
-            for (int j = 0; j < NF1; ++j) acc1[i][j] = X3Half<DT>::mfma(bh[j], al[i], acc1[i][j]);
+            for (int j = 0; j < NF1; ++j) { const int js = GPP_SERP2(i, j, NF1); acc1[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc1[i][js]); }
     }
 
     // ---- hand-over: everyone is done with the ring; W2 tile 0 streams in while the intermediate tile is written as pre-split rows
@@ -1859,13 +1871,14 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 3 : 2)) void bottleneck_tail_x3_ke
             for (int i = 0; i < MF2; ++i)
 #pragma unroll
                 for (int j = 0; j < NF2; ++j) {
-                    acc2[i][j] = X3Half<DT>::mfma(bl[j], ah[i], acc2[i][j]);
-                    acc2[i][j] = X3Half<DT>::mfma(bh[j], ah[i], acc2[i][j]);
+                    const int js = GPP_SERP2(i, j, NF2);
+                    acc2[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc2[i][js]);
+                    acc2[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc2[i][js]);
                 }
 #pragma unroll
             for (int i = 0; i < MF2; ++i)
 #pragma unroll
-                for (int j = 0; j < NF2; ++j) acc2[i][j] = X3Half<DT>::mfma(bh[j], al[i], acc2[i][j]);
+                for (int j = 0; j < NF2; ++j) { const int js = GPP_SERP2(i, j, NF2); acc2[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc2[i][js]); }
         }
         if (t + 1 < n2_tiles) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2081,13 +2094,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const gpp_conv_desc 
             for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    acc[i][j] = X3Half<DT>::mfma(bl[j], ah[i], acc[i][j]);
-                    acc[i][j] = X3Half<DT>::mfma(bh[j], ah[i], acc[i][j]);
+                    const int js = GPP_SERP2(i, j, NF);
+                    acc[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc[i][js]);
+                    acc[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc[i][js]);
                 }
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = X3Half<DT>::mfma(bh[j], al[i], acc[i][j]);
+                for (int j = 0; j < NF; ++j) { const int js = GPP_SERP2(i, j, NF); acc[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc[i][js]); }
             slot = (slot + 1) & (R - 1);
         }
         // ---- epilogue of tile c; the slabs of the next tiles are in flight underneath it

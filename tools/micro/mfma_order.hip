@@ -115,6 +115,67 @@ static double run(const f16x8* d_ops, float* d_sink, int iters)
     return ms;
 }
 
+// What a workgroup barrier per K-step costs the matrix pipe: the serpentine loop above with (BAR) one s_barrier per 96 MFMAs, as the conv
+// kernels have it, and (FILL) the ~40 scalar / vector instructions of the tap arithmetic after it.
+template <int BAR, int FILL>
+__global__ __launch_bounds__(512, 1) void x3_loop_bar(const f16x8* ops, int iters, float* sink, int one)
+{
+    const int lane = threadIdx.x & 63;
+    f16x8 ah[8], al[8], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ah[i] = ops[(i * 64 + lane) % 2048]; al[i] = ops[2048 + (i * 64 + lane) % 2048]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bh[j] = ops[4096 + (j * 64 + lane + 17) % 2048]; bl[j] = ops[6144 + (j * 64 + lane + 17) % 2048]; }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int t0 = lane, t1 = one, t2 = 3;
+    for (int it = 0; it < iters; ++it) {
+        FENCE();
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+#pragma unroll
+            for (int n = 0; n < 32; ++n) {
+                const int i = n / 4, j = (i & 1) ? 3 - n % 4 : n % 4;
+                if (term == 0) MFMA(bl, ah, i, j);
+                else if (term == 1) MFMA(bh, ah, i, j);
+                else MFMA(bh, al, i, j);
+                FENCE();
+            }
+            if (BAR && term == 1) { __builtin_amdgcn_s_barrier(); FENCE(); }
+        }
+        if constexpr (FILL) {
+#pragma unroll
+            for (int f = 0; f < 10; ++f) {               // 4 dependent integer instructions each
+                t0 = (t0 + t1) ^ t2;
+                t2 = t2 * one + (t0 == 77 ? 1 : 0);
+            }
+            FENCE();
+        }
+    }
+    float s = (float)(t0 + t2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int BAR, int FILL>
+static double run_bar(const f16x8* d_ops, float* d_sink, int iters)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0));
+    x3_loop_bar<BAR, FILL><<<256, 512>>>(d_ops, iters, d_sink, 1);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+}
+
 int main()
 {
     std::vector<uint16_t> h(8192 * 8);
@@ -144,6 +205,14 @@ int main()
                                 "row-major, middle term reversed", "column-major: 3 terms per weight fragment"};
         for (int o = 0; o < 9; ++o)
             printf("%-8s %-46s mean %.3f ms -> %7.1f TFLOP/s of MFMA = %6.1f of float32 products\n", pass ? "zeros" : "relu(A)", names[o], sum[o] / 6, flop / (sum[o] / 6) / 1e9, flop / (sum[o] / 6) / 3e9);
+        double sb[4] = {0, 0, 0, 0};
+        for (int rep = 0; rep < 6; ++rep) {
+            sb[0] += run_bar<0, 0>(d_ops, d_sink, iters); sb[1] += run_bar<1, 0>(d_ops, d_sink, iters);
+            sb[2] += run_bar<0, 1>(d_ops, d_sink, iters); sb[3] += run_bar<1, 1>(d_ops, d_sink, iters);
+        }
+        const char* nb[4] = {"serpentine, no barrier", "serpentine + s_barrier per K-step", "serpentine + 40 integer instructions per K-step", "serpentine + s_barrier + 40 integer instructions"};
+        for (int o = 0; o < 4; ++o)
+            printf("%-8s %-50s mean %.3f ms -> %7.1f TFLOP/s of MFMA\n", pass ? "zeros" : "relu(A)", nb[o], sb[o] / 6, flop / (sb[o] / 6) / 1e9);
     }
     return 0;
 }
