@@ -176,6 +176,87 @@ static double run_bar(const f16x8* d_ops, float* d_sink, int iters)
     return ms;
 }
 
+// Table-driven orders of the 32 accumulators of a phase (term-major, as the kernels' three phases): entry = 4 * activation fragment + weight fragment.
+struct Tab { int v[32]; };
+constexpr Tab make_tab(int kind)
+{
+    Tab t{};
+    int n = 0;
+    auto put = [&](int i, int j) { t.v[n++] = 4 * i + j; };
+    if (kind == 0) { for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) put(i, j); }                                    // rows, left to right
+    else if (kind == 1) { for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) put(i, (i & 1) ? 3 - j : j); }             // serpentine
+    else if (kind == 2) { for (int jb = 0; jb < 2; ++jb) for (int ib = 0; ib < 4; ++ib) { put(2 * ib, 2 * jb); put(2 * ib + 1, 2 * jb); put(2 * ib + 1, 2 * jb + 1); put(2 * ib, 2 * jb + 1); } }   // 2 x 2 blocks, column pair outer
+    else if (kind == 3) { for (int ib = 0; ib < 4; ++ib) for (int jb = 0; jb < 2; ++jb) { put(2 * ib, 2 * jb); put(2 * ib + 1, 2 * jb); put(2 * ib + 1, 2 * jb + 1); put(2 * ib, 2 * jb + 1); } }   // 2 x 2 blocks, row pair outer
+    else if (kind == 4) {                                                                                                       // 2-row bands, snake through the columns, bands alternate direction
+        for (int b = 0; b < 4; ++b) for (int c = 0; c < 4; ++c) { const int j = (b & 1) ? 3 - c : c; const bool up = (c & 1) != 0; put(2 * b + (up ? 1 : 0), j); put(2 * b + (up ? 0 : 1), j); }
+    }
+    else if (kind == 5) { for (int jb = 0; jb < 2; ++jb) for (int r = 0; r < 8; ++r) { const int i = (jb & 1) ? 7 - r : r; const bool rev = (r & 1) != 0; put(i, 2 * jb + (rev ? 1 : 0)); put(i, 2 * jb + (rev ? 0 : 1)); } }   // column pair outer, snake down the rows
+    else if (kind == 6) { for (int j = 0; j < 4; ++j) for (int r = 0; r < 8; ++r) put((j & 1) ? 7 - r : r, j); }                // columns, serpentine
+    else if (kind == 7) { for (int ib = 0; ib < 2; ++ib) for (int jb = 0; jb < 2; ++jb) for (int r = 0; r < 4; ++r) { const bool rev = (r & 1) != 0; put(4 * ib + r, 2 * jb + (rev ? 1 : 0)); put(4 * ib + r, 2 * jb + (rev ? 0 : 1)); } }   // 4 x 2 blocks
+    else if (kind == 8) { for (int ib = 0; ib < 4; ++ib) { for (int j = 0; j < 4; ++j) put(2 * ib, (ib & 1) ? 3 - j : j); for (int j = 0; j < 4; ++j) put(2 * ib + 1, (ib & 1) ? j : 3 - j); } }        // = serpentine (check)
+    else { for (int d = 0; d < 32; ++d) put(d % 8, (d + d / 8) % 4); }                                                          // diagonal: both change
+    return t;
+}
+
+constexpr bool is_permutation(Tab t)
+{
+    unsigned seen = 0;
+    for (int n = 0; n < 32; ++n) { if (t.v[n] < 0 || t.v[n] > 31) return false; seen |= 1u << t.v[n]; }
+    return seen == 0xffffffffu;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(512, 1) void x3_loop_tab(const f16x8* ops, int iters, float* sink)
+{
+    constexpr Tab T = make_tab(KIND);
+    static_assert(is_permutation(T), "every accumulator once per phase");
+    const int lane = threadIdx.x & 63;
+    f16x8 ah[8], al[8], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ah[i] = ops[(i * 64 + lane) % 2048]; al[i] = ops[2048 + (i * 64 + lane) % 2048]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bh[j] = ops[4096 + (j * 64 + lane + 17) % 2048]; bl[j] = ops[6144 + (j * 64 + lane + 17) % 2048]; }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        FENCE();
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+#pragma unroll
+            for (int n = 0; n < 32; ++n) {
+                constexpr int dummy = 0; (void)dummy;
+                const int i = T.v[n] / 4, j = T.v[n] % 4;
+                if (term == 0) MFMA(bl, ah, i, j);
+                else if (term == 1) MFMA(bh, ah, i, j);
+                else MFMA(bh, al, i, j);
+                FENCE();
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int KIND>
+static double run_tab(const f16x8* d_ops, float* d_sink, int iters)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0));
+    x3_loop_tab<KIND><<<256, 512>>>(d_ops, iters, d_sink);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+}
+
 int main()
 {
     std::vector<uint16_t> h(8192 * 8);
@@ -205,6 +286,18 @@ int main()
                                 "row-major, middle term reversed", "column-major: 3 terms per weight fragment"};
         for (int o = 0; o < 9; ++o)
             printf("%-8s %-46s mean %.3f ms -> %7.1f TFLOP/s of MFMA = %6.1f of float32 products\n", pass ? "zeros" : "relu(A)", names[o], sum[o] / 6, flop / (sum[o] / 6) / 1e9, flop / (sum[o] / 6) / 3e9);
+        double st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int rep = 0; rep < 6; ++rep) {
+            st[0] += run_tab<0>(d_ops, d_sink, iters); st[1] += run_tab<1>(d_ops, d_sink, iters); st[2] += run_tab<2>(d_ops, d_sink, iters);
+            st[3] += run_tab<3>(d_ops, d_sink, iters); st[4] += run_tab<4>(d_ops, d_sink, iters); st[5] += run_tab<5>(d_ops, d_sink, iters);
+            st[6] += run_tab<6>(d_ops, d_sink, iters); st[7] += run_tab<7>(d_ops, d_sink, iters); st[8] += run_tab<8>(d_ops, d_sink, iters);
+            st[9] += run_tab<9>(d_ops, d_sink, iters);
+        }
+        const char* nt[10] = {"table: rows, left to right", "table: serpentine", "table: 2 x 2 blocks, column pair outer", "table: 2 x 2 blocks, row pair outer",
+                              "table: 2-row bands, snake", "table: column pairs, snake down the rows", "table: columns, serpentine", "table: 4 x 2 blocks",
+                              "table: serpentine by row pairs (= serpentine)", "table: diagonal"};
+        for (int o = 0; o < 10; ++o)
+            printf("%-8s %-50s mean %.3f ms -> %7.1f TFLOP/s of MFMA\n", pass ? "zeros" : "relu(A)", nt[o], st[o] / 6, flop / (st[o] / 6) / 1e9);
         double sb[4] = {0, 0, 0, 0};
         for (int rep = 0; rep < 6; ++rep) {
             sb[0] += run_bar<0, 0>(d_ops, d_sink, iters); sb[1] += run_bar<1, 0>(d_ops, d_sink, iters);
