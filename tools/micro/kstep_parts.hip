@@ -16,6 +16,7 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -31,7 +32,7 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int voffset,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, voffset, 0, 0, AUX);
 }
 
-template <int READS, int DMA, int BAR, int NW = 8, int AUX = 0>
+template <int READS, int DMA, int BAR, int NW = 8, int AUX = 0, int ASHARE = 1>
 __global__ __launch_bounds__(NW * 64, 1) void kstep(const unsigned char* image, int iters, float* sink)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -69,7 +70,9 @@ __global__ __launch_bounds__(NW * 64, 1) void kstep(const unsigned char* image, 
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);                                 // as the kernel: the second wavefront of every SIMD goes first
-    for (int ks = 0; ks < iters; ++ks) {
+    // (ASHARE 3: the activation rows of three K-steps -- the horizontal taps of a kernel row -- in one transfer: three copies of the body, the first one moves them)
+    auto step = [&](const int ks, auto share_tag) {
+        constexpr bool share_now = decltype(share_tag)::value;
         const int cur = ks & 1;
         const unsigned char* scur = smem + cur * kStage;
         const unsigned char* snxt = smem + (cur ^ 1) * kStage;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(NW * 64, 1) void kstep(const unsigned char* image, 
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
 #pragma unroll
-            for (int q = g * PC / 8; q < (g + 1) * PC / 8; ++q) if (DMA) glds16<AUX>(rsrc, a_off(q) + lane * 16, smem + cur * kStage + a_off(q));
+            for (int q = g * PC / 8; q < (g + 1) * PC / 8; ++q) if (DMA && (ASHARE == 1 || share_now)) glds16<AUX>(rsrc, a_off(q) + lane * 16, smem + cur * kStage + a_off(q));
             if (READS) {
                 ah[g] = *(const f16x8*)(snxt + a_rd[0] + g * 16 * kRow);
 #pragma unroll
@@ -111,6 +114,11 @@ __global__ __launch_bounds__(NW * 64, 1) void kstep(const unsigned char* image, 
             for (int j = 0; j < NF; ++j) { const int js = (g & 1) ? NF - 1 - j : j; acc[g][js] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[js], al[g], acc[g][js], 0, 0, 0); }
             FENCE();
         }
+    };
+    if constexpr (ASHARE == 1) {
+        for (int ks = 0; ks < iters; ++ks) step(ks, std::true_type{});
+    } else {
+        for (int ks = 0; ks + 2 < iters; ks += 3) { step(ks, std::true_type{}); step(ks + 1, std::false_type{}); step(ks + 2, std::false_type{}); }
     }
     __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -125,16 +133,16 @@ __global__ __launch_bounds__(NW * 64, 1) void kstep(const unsigned char* image, 
 static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
 static float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 
-template <int READS, int DMA, int BAR, int NW = 8, int AUX = 0>
+template <int READS, int DMA, int BAR, int NW = 8, int AUX = 0, int ASHARE = 1>
 static double run(const unsigned char* d_img, float* d_sink, int iters)
 {
     static bool once = false;
     if (!once) { once = true; }
-    CHECK(hipFuncSetAttribute((const void*)kstep<READS, DMA, BAR, NW, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
+    CHECK(hipFuncSetAttribute((const void*)kstep<READS, DMA, BAR, NW, AUX, ASHARE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStage));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     CHECK(hipEventRecord(e0));
-    kstep<READS, DMA, BAR, NW, AUX><<<256, NW * 64, 2 * kStage>>>(d_img, iters, d_sink);
+    kstep<READS, DMA, BAR, NW, AUX, ASHARE><<<256, NW * 64, 2 * kStage>>>(d_img, iters, d_sink);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipGetLastError());
@@ -170,18 +178,20 @@ int main()
         CHECK(hipMemcpy(d_img, h.data(), bytes, hipMemcpyHostToDevice));
         const int iters = 6000;
         const double flop = 256.0 * 8 * iters * 96 * 2.0 * 16 * 16 * 32;
-        double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double sum[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         run<0, 0, 0>(d_img, d_sink, 300);
         for (int rep = 0; rep < 5; ++rep) {
             sum[0] += run<0, 0, 0>(d_img, d_sink, iters); sum[1] += run<0, 0, 1>(d_img, d_sink, iters); sum[2] += run<1, 0, 1>(d_img, d_sink, iters);
             sum[3] += run<0, 1, 1>(d_img, d_sink, iters); sum[4] += run<1, 1, 1>(d_img, d_sink, iters); sum[5] += run<1, 1, 0>(d_img, d_sink, iters);
             sum[6] += run<0, 0, 1, 4>(d_img, d_sink, iters); sum[7] += run<1, 0, 1, 4>(d_img, d_sink, iters); sum[8] += run<1, 1, 1, 4>(d_img, d_sink, iters);
             sum[9] += run<1, 1, 1, 8, 1>(d_img, d_sink, iters); sum[10] += run<1, 1, 1, 8, 2>(d_img, d_sink, iters); sum[11] += run<1, 1, 1, 8, 3>(d_img, d_sink, iters);
+            sum[12] += run<1, 1, 1, 8, 0, 3>(d_img, d_sink, iters);
         }
-        const char* names[12] = {"MFMAs only", "+ s_barrier", "+ s_barrier + 24 LDS reads", "+ s_barrier + 8 LDS-DMA", "+ s_barrier + reads + DMA (the kernel's K-step)", "reads + DMA, no barrier (unsafe, timing only)",
+        const char* names[13] = {"MFMAs only", "+ s_barrier", "+ s_barrier + 24 LDS reads", "+ s_barrier + 8 LDS-DMA", "+ s_barrier + reads + DMA (the kernel's K-step)", "reads + DMA, no barrier (unsafe, timing only)",
                                 "4 wavefronts of 128 x 128: MFMAs + s_barrier", "4 wavefronts: + 32 LDS reads each (2/3 of the bytes)", "4 wavefronts: + reads + 16 LDS-DMA each",
-                                "the kernel's K-step, LDS-DMA with cache policy sc0", "the kernel's K-step, LDS-DMA with cache policy nt", "the kernel's K-step, LDS-DMA with sc0 + nt"};
-        for (int o = 0; o < 12; ++o)
+                                "the kernel's K-step, LDS-DMA with cache policy sc0", "the kernel's K-step, LDS-DMA with cache policy nt", "the kernel's K-step, LDS-DMA with sc0 + nt",
+                                "the kernel's K-step, activation rows moved every 3rd step only"};
+        for (int o = 0; o < 13; ++o)
             printf("%-8s %-52s mean %.3f ms  K-step %.3f us -> %7.1f TFLOP/s of MFMA = %5.1f of float32 products\n", pass ? "zeros" : "relu(A)", names[o], sum[o] / 5,
                    sum[o] / 5 / iters * 1e3, flop / (sum[o] / 5) / 1e9, flop / (sum[o] / 5) / 3e9);
     }
