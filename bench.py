@@ -330,12 +330,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     gather_wait_s[0] = 0.0
+    from keras_retinanet_3D.utils import devmon
+    monitor = devmon.Sampler(local_rank if distributed else 0)     # (a thread reading sysfs files: no GPU call, nothing in the step's way)
+    monitor.__enter__()
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = step(k)
     wait_pending()                                             # the last gather completes inside the timed region
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0                     # this rank alone, before it waits for the others
+    monitor.__exit__(None, None, None)
+    device_state = monitor.summary()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -600,6 +605,13 @@ def main():
                                                           'which the pipe reaches on all-zero operands only')
         if traffic_note:
             rec['roofline']['traffic_note'] = traffic_note
+        if device_state:
+            # what the driver reported for rank 0's card during the timed region: `peak` is the figure at the nominal 2400 MHz; the matrix pipe's peak
+            # at the clock the power management actually granted is peak x sclk / 2400.  The median is over the WHOLE step; under the dominant kernel alone the
+            # clock is lower still (tools/clock_under_load.py: 2006 MHz at 1395 W of 1400 on real data, 2398 MHz on zeros -- profiles/r4/clock_under_load.txt)
+            rec['roofline']['device_during_timed_region'] = device_state
+            if device_state.get('sclk_mhz_median'):
+                rec['roofline']['frac_at_the_steps_median_clock'] = round(achieved / (PEAK_TFLOPS[args.dtype] * device_state['sclk_mhz_median'] / 2400.0), 4)
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'], exact = cpu_baseline(args.cpu_images, args.backbone, planes, replay)
             rec['config']['gpu_decode_polling_replay_bit_exact'] = exact
