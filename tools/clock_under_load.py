@@ -153,8 +153,72 @@ def main():
             if v:
                 line += '   %s: median %.0f, min %.0f, max %.0f %s (%d samples)' % (key.split('_')[0], v[len(v) // 2], v[0], v[-1], unit, len(v))
         print(line)
+    # an HBM-bound layer of the backbone (res2x branch2a, 1 x 1, 256 -> 64 on the 101 x 334 map: 345 MB per launch) and the whole step, for contrast
+    def under_load(name, launch, work_note):
+        stop = threading.Event()
+        count = [0]
+
+        def load():
+            torch.cuda.set_device(0)
+            while not stop.is_set():
+                for _ in range(10):
+                    launch()
+                torch.cuda.synchronize()
+                count[0] += 10
+
+        t = threading.Thread(target=load)
+        t0 = time.perf_counter()
+        t.start()
+        samples = []
+        time.sleep(0.5)
+        n0, ts0 = count[0], time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            rec = read_sysfs(src[card]) if card else read_smi()
+            if rec:
+                samples.append(rec)
+            time.sleep(0.05)
+        n1, ts1 = count[0], time.perf_counter()
+        stop.set()
+        t.join()
+        us = (ts1 - ts0) / max(1, n1 - n0) * 1e6
+        line = '%-40s %8.1f us per launch %s' % (name, us, work_note(us))
+        for key, unit in (('sclk_mhz', 'MHz'), ('power_w', 'W')):
+            v = sorted(s[key] for s in samples if key in s)
+            if v:
+                line += '   %s: median %.0f, min %.0f, max %.0f %s' % (key.split('_')[0], v[len(v) // 2], v[0], v[-1], unit)
+        print(line)
+
+    H2, W2 = 101, 334
+    xb = torch.empty((B, H2 * W2, 256), device=dev)
+    yb = torch.empty((B, H2 * W2, 64), device=dev)
+    fi = C.FMap(xb, B, H2, W2, 256, split=True, half=dtype)
+    fo = C.FMap(yb, B, H2, W2, 64, split=True, half=dtype)
+    fi.write(torch.relu(torch.randn((B, H2, W2, 256), device=dev)))
+    wk1 = (torch.randn((1, 1, 256, 64)) * 0.05).numpy()
+    d1 = C.conv_desc([fi], [fo], C.pack_weight(wk1, dtype, dev), torch.zeros((64,), device=dev), 1, 1, 256, 64, relu=True, dtype=dtype, tile_hint=4064064,
+                     out_scale=C.out_scale_of(wk1, dev))
+    mb = (xb.numel() + yb.numel()) * 4 / 1e6
+    under_load('res2x branch2a 1x1 256->64 (HBM-bound)', lambda: C.run_conv(d1), lambda us: '= %.2f TB/s of compulsory bytes' % (mb / us))
+
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from keras_retinanet_3D import models
+    from keras_retinanet_3D.utils import synthetic
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype=dtype)
+    planes = synthetic.load_plane_database('1k').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    images = torch.as_tensor(bench.synthetic_batch(B, 0)).cuda()
+    P = torch.as_tensor(np.tile(P_inv[None].astype(np.float32), (B, 1, 1))).cuda()
+    pl = torch.as_tensor(np.tile(planes[None], (B, 1, 1))).cuda()
+    plan = model.stage_inputs([images, P, pl])
+    for _ in range(3):
+        model.run_plan(plan)
+    torch.cuda.synchronize()
+    under_load('the whole step (default plan, B = 8)', lambda: model.run_plan(plan), lambda us: '= %.1f images/s' % (B / us * 1e6))
+    time.sleep(1.0)
     idle = read_sysfs(src[card]) if card else read_smi()
-    print('idle afterwards:', idle)
+    print('idle, one second later:', idle)
 
 
 if __name__ == '__main__':
