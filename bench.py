@@ -72,6 +72,8 @@ def parse():
     p.add_argument('--no-f32-leg', action='store_true', help='skip the float32 leg + parity ledger of a 16-bit run')
     p.add_argument('--no-host-fed', action='store_true', help='skip the host-fed (PCIe-inclusive) legs')
     p.add_argument('--cpu-images', type=int, default=4, help='frames of the bounded CPU-baseline sample (about 3.5 s each on 128 host threads)')
+    p.add_argument('--no-b1', action='store_true', help='skip the batch-1 synchronous latency leg (config.b1)')
+    p.add_argument('--repeats', type=int, default=3, help='further timed repeats of the K steps after the headline loop (config.repeat_images_per_s)')
     p.add_argument('--dry-launch', action='store_true',
                    help='rehearse the rank launcher without a GPU: every rank joins a gloo group, gathers a packed (B,100,35) tensor and exits')
     return p.parse_args()
@@ -133,6 +135,31 @@ class c_stdout_to_stderr(object):
         return False
 
 
+DIAG_KEYS = ('ms_per_step', 'gather_wait_ms_per_step', 'sclk_mhz_median', 'power_w_median', 'power_cap_w', 'model_load_s', 'plan_build_and_tune_s')
+
+
+def diagnose_over_ranks(local, device):
+    """ every rank's own figures (DIAG_KEYS; a missing one is NaN) -> per key the list over ranks + min / median / max: what a reader of
+    a non-linear scaling curve looks at first -- a slow rank, a card at a lower clock under the same power cap, an exposed gather,
+    a rank that was still tuning.  One all_gather of len(DIAG_KEYS) doubles, outside the timed region. """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    mine = torch.tensor([float(local.get(k, float('nan'))) if local.get(k) is not None else float('nan') for k in DIAG_KEYS],
+                        dtype=torch.float64, device=device)
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    table = torch.stack(allv).cpu().numpy()                       # (world, keys)
+    out = {'ranks': world}
+    for j, k in enumerate(DIAG_KEYS):
+        col = table[:, j]
+        ok = col[np.isfinite(col)]
+        out[k] = {'per_rank': [None if not np.isfinite(v) else round(float(v), 4) for v in col],
+                  'min': None if not len(ok) else round(float(ok.min()), 4), 'median': None if not len(ok) else round(float(np.median(ok)), 4),
+                  'max': None if not len(ok) else round(float(ok.max()), 4)}
+    return out
+
+
 def dry_launch(args, rank, world):
     """ what a rank does under --dry-launch: the rendezvous + the one collective of the path on gloo, no GPU """
     import torch
@@ -145,10 +172,13 @@ def dry_launch(args, rank, world):
         packed = torch.full((args.batch, 100, D.PACK_WIDTH), float(rank), dtype=torch.float32)
         out = D.gather_detections(packed, [args.batch] * world)
     ok = all(bool((out[r * args.batch:(r + 1) * args.batch] == float(r)).all()) for r in range(world))
+    # the diagnosis block of a real multi-GPU line, rehearsed with stand-in figures (rank r reports r in every field it has)
+    with c_stdout_to_stderr():
+        diag = diagnose_over_ranks({k: float(rank) for k in DIAG_KEYS if k != 'power_cap_w'}, torch.device('cpu'))
     dist.barrier()
     if rank == 0:
         print(json.dumps({'dry_launch': True, 'n_gpus': world, 'world_size': dist.get_world_size(), 'gpus_requested': args.gpus,
-                          'gathered_images_per_step': int(out.shape[0]), 'gather_correct': ok}))
+                          'gathered_images_per_step': int(out.shape[0]), 'gather_correct': ok, 'multi_gpu_diagnosis': diag}))
     dist.destroy_process_group()
     return 0 if ok else 1
 
@@ -270,14 +300,20 @@ def main():
     from keras_retinanet_3D.utils import ledger
     import ctypes
 
+    t_load = time.perf_counter()
     model = models.load_model('synthetic:1234', backbone_name=args.backbone, dtype=args.dtype)
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t_load
     planes = synthetic.load_plane_database(args.planes).astype(np.float32)
     _, P_inv = synthetic.synthetic_calibration()
     B = args.batch
     images = torch.as_tensor(synthetic_batch(B, rank)).cuda()
     P_inv_d = torch.as_tensor(np.tile(P_inv[None].astype(np.float32), (B, 1, 1))).cuda()
     planes_d = torch.as_tensor(np.tile(planes[None], (B, 1, 1))).cuda()      # tiled per image, as kitti.py:220
-    plan = model.stage_inputs([images, P_inv_d, planes_d])                    # inputs resident in HBM from here on
+    t_plan = time.perf_counter()
+    plan = model.stage_inputs([images, P_inv_d, planes_d])                    # inputs resident in HBM from here on (first call: plan build + tile timing)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t_plan
     # RESIDENT_BATCHES distinct batches of frames live in HBM; step k reads batch k mod RESIDENT_BATCHES (the stem's input pointer is
     # switched on the host, nothing is copied): the 51 MB of input are not served from the Infinity Cache step after step.
     # Batch 0 (the plan's own buffer) is the one the ledger legs and the oracle replay use; the last timed step lands on it.
@@ -350,36 +386,65 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # diagnosis of a scaling run: every rank's own time for its K steps (min / max over ranks) and the host time it spent
-        # blocked on the previous step's gather (exposed collective time; the gather itself overlaps the next step's kernels)
-        lo = torch.tensor([own_elapsed, gather_wait_s[0]], dtype=torch.float64, device='cuda')
-        hi = lo.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        per_rank = {'ms_per_step_min_over_ranks': round(1e3 * float(lo[0]) / args.steps, 3),
-                    'ms_per_step_max_over_ranks': round(1e3 * float(hi[0]) / args.steps, 3),
-                    'gather_wait_ms_per_step_min_over_ranks': round(1e3 * float(lo[1]) / args.steps, 4),
-                    'gather_wait_ms_per_step_max_over_ranks': round(1e3 * float(hi[1]) / args.steps, 4)}
+        # diagnosis of a scaling run, rank by rank: its own time for its K steps, the host time it spent blocked on the previous step's
+        # gather (exposed collective time; the gather itself overlaps the next step's kernels), the clock and power the driver granted
+        # ITS card during the timed region (eight boards that each want the 1400 W cap are the first suspect of a non-linear curve),
+        # and how long it took to load the model and to build + tune its plan
+        ds = device_state or {}
+        per_rank = diagnose_over_ranks({'ms_per_step': 1e3 * own_elapsed / args.steps, 'gather_wait_ms_per_step': 1e3 * gather_wait_s[0] / args.steps,
+                                        'sclk_mhz_median': ds.get('sclk_mhz_median'), 'power_w_median': ds.get('power_w_median'),
+                                        'power_cap_w': ds.get('power_cap_w'), 'model_load_s': t_load, 'plan_build_and_tune_s': t_plan},
+                                       torch.device('cuda', local_rank))
+        per_rank['ms_per_step_min_over_ranks'] = per_rank['ms_per_step']['min']
+        per_rank['ms_per_step_max_over_ranks'] = per_rank['ms_per_step']['max']
+        per_rank['gather_wait_ms_per_step_min_over_ranks'] = per_rank['gather_wait_ms_per_step']['min']
+        per_rank['gather_wait_ms_per_step_max_over_ranks'] = per_rank['gather_wait_ms_per_step']['max']
     gathered_images = int(out.shape[0]) if out is not None else B
     rccl_world = dist.get_world_size() if distributed else 1
     if rccl_world != args.gpus:
         raise SystemExit('RCCL reports {} ranks, --gpus {} was asked for'.format(rccl_world, args.gpus))
 
     # dominant kernel: mean launch duration from the HIP events recorded inside the timed region
-    durations = []
-    for i in range(0, len(events), 2):
-        ms = ctypes.c_float(0.0)
-        hip.check(lib.gpp_event_elapsed_ms(events[i], events[i + 1], ctypes.byref(ms)))
-        durations.append(ms.value)
     tags = [tag for _, tag, _, _, _ in plan.ops if tag]                   # per step: the tagged ops in launch order
-    by_tag = {}
-    for i, ms_ in enumerate(durations):
-        by_tag.setdefault(tags[i % len(tags)], []).append(ms_)
+
+    def read_events():
+        by = {}
+        for i in range(0, len(events), 2):
+            ms = ctypes.c_float(0.0)
+            hip.check(lib.gpp_event_elapsed_ms(events[i], events[i + 1], ctypes.byref(ms)))
+            by.setdefault(tags[(i // 2) % len(tags)], []).append(ms.value)
+        return by
+
+    by_tag = read_events()
     tagged_flops = [fl for _, tag, _, _, fl in plan.ops if tag == 1]       # tag 1 = the regression-tower launches
     flops_per_launch = float(np.mean(tagged_flops)) if tagged_flops else 0.0
     durations = by_tag.get(1, [])
     mean_ms = float(np.mean(durations)) if durations else float('nan')
     achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12 if durations else float('nan')
+
+    # the line's own error bar (reported, never `value`): the same K steps timed again --repeats times, same bracket (barrier +
+    # synchronize on both sides, max over ranks), same rotation over the resident batches, the dominant kernel's events read per repeat
+    repeat_rates, repeat_fracs = [], []
+    for _ in range(max(0, args.repeats)):
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            out = step(k)
+        wait_pending()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        repeat_rates.append(round(world * B * args.steps / dt, 2))
+        d1 = read_events().get(1, [])
+        repeat_fracs.append(round(flops_per_launch / (float(np.mean(d1)) * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4) if d1 else None)
     # polling (tag 2 = canonical planes + poll kernel): the three figures SURVEY 8(d) asks for, from the same live events
     polling = None
     if by_tag.get(2):
@@ -530,6 +595,13 @@ def main():
         torch.cuda.synchronize()
         host_frames_resident = round(B * n_it / (time.perf_counter() - t1), 1)
 
+    # the reference's own timer (bin/run_network.py:108-111): ONE synchronous batch-1 predict_on_batch, upload and fetch inside the bracket
+    b1 = None
+    if extras and not args.no_b1:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import b1_latency
+        b1 = b1_latency.measure(model, planes, n=40)
+
     if rank == 0:
         total_images = world * B * args.steps
         reg_tile = getattr(plan, 'tuning', {}).get('pyramid_regression_1', (0, 0.0))[0]
@@ -572,6 +644,13 @@ def main():
                        'resident_batches_rotated': RESIDENT_BATCHES,
                        'side_stream_launches': dict(getattr(plan, 'side_lanes', {}), decode=bool(getattr(plan, 'decode_overlap', False))),
                        'multi_gpu_diagnosis': per_rank,
+                       'step_contents_note': 'a 1-GPU step is the plan alone (its eight result arrays are the plan\'s output buffers); an N > 1 step adds '
+                                             'one pack launch (gpp_pack_detections, ~5 us) and the asynchronous all_gather of (B,100,35) per rank',
+                       'repeat_images_per_s': repeat_rates or None,
+                       'repeat_spread_pct': None if not repeat_rates else round(100.0 * (max(repeat_rates + [round(total_images / elapsed, 2)]) -
+                                                                                          min(repeat_rates + [round(total_images / elapsed, 2)])) /
+                                                                                (total_images / elapsed), 2),
+                       'b1': b1,
                        'other_types_same_frames': other_legs or None,
                        'host_fed_synchronous_images_per_s_incl_pcie_and_gpu_preprocessing': pcie_rate,
                        'host_fed_streaming_images_per_s': pcie_pipelined,
@@ -593,6 +672,7 @@ def main():
                                                                for i in (1, 2, 3)))), B * (plan.n_anchors // 12)),
                          'gflop_per_launch': round(flops_per_launch / 1e9, 1), 'mean_launch_ms': round(mean_ms, 4),
                          'launches_timed': len(durations), 'timed_on_steps': 'every {}rd of the {} timed steps'.format(EVENT_EVERY, args.steps),
+                         'frac_per_repeat': repeat_fracs or None,
                          'library': version},
         }
         if args.dtype in PIPE_ON_RANDOM_DATA_TFLOPS:

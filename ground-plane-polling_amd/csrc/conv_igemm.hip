@@ -130,6 +130,12 @@ extern "C" int gpp_x3_range_events(uint64_t* host_count, int reset)
     return rc;
 }
 
+extern "C" int gpp_x3_range_snapshot(uint64_t* device_count, void* stream)
+{
+    if (!device_count) return GPP_ERR_BAD_ARG;
+    return gpp_x3_range_snapshot_f16x3((unsigned long long*)device_count, (hipStream_t)stream);
+}
+
 extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)
 {
     if (!host_desc || !flops) return GPP_ERR_BAD_ARG;

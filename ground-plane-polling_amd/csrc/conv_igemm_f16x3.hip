@@ -26,3 +26,21 @@ int gpp_x3_range_events_f16x3(unsigned long long* host_count, int reset)
     }
     return GPP_OK;
 }
+
+// the counter's value at this point of the stream, written to device (or device-visible host) memory: no synchronisation
+__global__ void x3_range_snapshot_kernel(unsigned long long* dst) { *dst = g_x3_range_events; }
+
+int gpp_x3_range_snapshot_f16x3(unsigned long long* device_count, hipStream_t st)
+{
+    hipLaunchKernelGGL(x3_range_snapshot_kernel, dim3(1), dim3(1), 0, st, device_count);
+    return (int)hipGetLastError();
+}
+
+// device address of the counter on the current device (the x3 stem of stem.hip counts into it too: its float32 output map is split --
+// and clamped -- by the first bottleneck's loop, which has no epilogue of its own to count in)
+unsigned long long* gpp_x3_range_counter_f16x3()
+{
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_x3_range_events)) != hipSuccess) return nullptr;
+    return (unsigned long long*)p;
+}

@@ -19,6 +19,7 @@
 #include <atomic>
 
 #include "gpp.h"
+#include "conv_igemm_types.h"
 
 namespace {
 
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
 template <int ROWS>
 __global__ __launch_bounds__(64 * ROWS) void stem_mfma_x3_kernel(const float* __restrict__ in, const _Float16* __restrict__ w,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
-                                                                 int B, int H, int W, int Ho, int Wo)
+                                                                 int B, int H, int W, int Ho, int Wo, unsigned long long* range_events)
 {
     constexpr int NT = 64 * ROWS, PROWS = ROWS * 2 + 5;
     constexpr int W_HALFS = 64 * MW_PITCH;
@@ -352,6 +353,12 @@ __global__ __launch_bounds__(64 * ROWS) void stem_mfma_x3_kernel(const float* __
                     }
                     *(f32x4*)(dst + jj * 32 + fq * 8) = v0;
                     *(f32x4*)(dst + jj * 32 + fq * 8 + 4) = v1;
+                    // GPP_F16X3 range ledger (conv_igemm_impl.h x3_range): this map is stored as float32 and split -- clamped to the half
+                    // range -- by the loop of the layers that read it; a value they would alter (or a NaN) is counted here
+                    bool outside = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) outside |= !(v0[e] <= 65504.0f) | !(v1[e] <= 65504.0f);
+                    if (__builtin_expect(outside, 0)) atomicAdd(range_events, 1ull);
                 }
             }
         }
@@ -695,7 +702,14 @@ extern "C" int gpp_stem_conv7x7_bn_relu_x3(const float* in, const void* packed_w
         configured.fetch_or(1ull << dev, std::memory_order_release);
     }
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);                           // persistent workgroups, one per CU
-    stem_mfma_x3_kernel<ROWS><<<grid, 64 * ROWS, lds, (hipStream_t)stream>>>(in, (const _Float16*)packed_weight_x3, bias, out, B, H, W, Ho, Wo);
+    static std::atomic<unsigned long long*> counter_of_device[64];
+    unsigned long long* counter = counter_of_device[dev].load(std::memory_order_acquire);
+    if (!counter) {
+        counter = gpp_x3_range_counter_f16x3();
+        if (!counter) return GPP_ERR_UNSUPPORTED;
+        counter_of_device[dev].store(counter, std::memory_order_release);
+    }
+    stem_mfma_x3_kernel<ROWS><<<grid, 64 * ROWS, lds, (hipStream_t)stream>>>(in, (const _Float16*)packed_weight_x3, bias, out, B, H, W, Ho, Wo, counter);
     return result();
 }
 

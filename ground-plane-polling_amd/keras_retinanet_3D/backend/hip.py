@@ -130,6 +130,8 @@ def _declare(lib):
     lib.gpp_conv2d_tile_candidates.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int)]
     lib.gpp_x3_range_events.restype = c_int
     lib.gpp_x3_range_events.argtypes = [ctypes.POINTER(ctypes.c_uint64), c_int]
+    lib.gpp_x3_range_snapshot.restype = c_int
+    lib.gpp_x3_range_snapshot.argtypes = [c_void_p, c_void_p]
     lib.gpp_conv2d_autotune.restype = c_int
     lib.gpp_conv2d_autotune.argtypes = [ctypes.POINTER(ConvDesc), c_int, c_void_p, ctypes.POINTER(c_float)]
 

@@ -7,7 +7,9 @@ Model loading surface of the reference, kept name for name for the inference pat
 
 `filepath` may be
     'synthetic:<seed>'   seeded random weights of the exact architecture (no trained weights ship
-                         with the reference, README.md:75)
+                         with the reference, README.md:75); 'synthetic:<seed>:trained' = the same draw with the activation statistics
+                         of a trained checkpoint (per-channel scales three decades apart, dead channels, a residual stream that
+                         grows stage by stage: models/weights.trained_like)
     '<file>.npz'         weights saved by models.weights.save_weights (Keras layer names)
     '<file>.h5'          a Keras model (`model.save`) or weight (`model.save_weights`) file, the format the reference reads and
                          writes (bin/convert_model.py:50-53): h5py when importable, else libhdf5 through ctypes (models/hdf5.py)
@@ -42,7 +44,7 @@ def backbone(backbone_name):
 
 
 def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, class_specific_filter=True,
-               orientation_specific_filter=False, dtype=None):
+               orientation_specific_filter=False, dtype=None, on_range_event=None):
     """ Loads a RetinaNet-3D inference model (reference models/__init__.py:59-88).
 
     `convert` is accepted for signature compatibility: every model this function returns already
@@ -53,6 +55,10 @@ def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, clas
         'f32'              float32 storage and operands (the reference's floatx, /root/reference/keras_retinanet_3D/utils/image.py:47)
         'bf16x3'           three bf16 products per float32 product (~2^-16): same detections and planes, corners off by millimetres
         'f16' | 'bf16'     16-bit storage and MFMA operands, float32 accumulation: 2.4x faster, a few percent of the detections differ
+    `on_range_event` (not in the reference; dtype='f16x3' only; None = the environment's GPP_ON_RANGE_EVENT, else 'f32'): what a call does
+    when one of its activations left the IEEE-half range (beyond +-65504: clamped, counted by the kernels' epilogues) --
+        'f32' (default)    the call is run again on a float32 twin of the model and THAT result is returned (the reference's answer, slower)
+        'raise'            GppError;      'ignore'   the clamped result is returned (model.x3_range_events() still counts)
     """
     import os
     if dtype is None:
@@ -64,14 +70,12 @@ def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, clas
     if isinstance(filepath, dict):
         w = filepath
     elif isinstance(filepath, str) and filepath.startswith('synthetic'):
-        import re
-        m = re.match(r'synthetic:(\d+)', filepath)          # 'synthetic:7', also 'synthetic:7.h5' (run_network strips 3 chars)
-        seed = int(m.group(1)) if m else 1234
-        w = W.synthetic_weights(name, seed)
+        seed, family = W.parse_synthetic(filepath)         # 'synthetic:7', 'synthetic:7:trained', also 'synthetic:7.h5' (run_network strips 3 chars)
+        w = W.synthetic_weights(name, seed, family)
     else:
         w = W.load_weights(filepath)
     model = RetinaNet3D(w, backbone_name=name, dtype=dtype, nms=nms, class_specific_filter=class_specific_filter,
-                        orientation_specific_filter=orientation_specific_filter)
+                        orientation_specific_filter=orientation_specific_filter, on_range_event=on_range_event)
     if convert:
         model.summary()
     return model

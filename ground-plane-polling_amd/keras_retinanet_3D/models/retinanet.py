@@ -176,8 +176,23 @@ class RetinaNet3D(object):
     """ Inference model: ResNet-50/101/152 + FPN + heads + decode + ground-plane polling. """
 
     def __init__(self, weights, backbone_name='resnet50', dtype='f16x3', nms=True, class_specific_filter=True,
-                 orientation_specific_filter=False, name='retinanet-bbox'):
+                 orientation_specific_filter=False, name='retinanet-bbox', on_range_event=None):
         import torch
+        # dtype='f16x3' only -- what happens when an activation of a call left the IEEE-half range (a finite value beyond +-65504 is
+        # clamped when it is split: a plausible wrong answer; the epilogues count such stores, gpp_x3_range_events):
+        #   'f32' (default)  the call is run again at dtype='f32' (a float32 twin of the model, built at the first event) and THAT result
+        #                    is returned: the drop-in returns what the reference's floatx graph returns, slower for that call
+        #   'raise'          GppError
+        #   'ignore'         rounds 3-4: the counter is only there to be read (model.x3_range_events())
+        # The counter is read with the results a synchronous call fetches anyway (fetch(), FramePipeline): no extra synchronisation.
+        self.on_range_event = on_range_event or os.environ.get('GPP_ON_RANGE_EVENT', 'f32')
+        if self.on_range_event not in ('f32', 'raise', 'ignore'):
+            raise ValueError("on_range_event must be 'f32', 'raise' or 'ignore', got {!r}".format(self.on_range_event))
+        self.range_fallbacks = 0         # calls whose result was replaced (or refused) because of a range event
+        self._range_seen = 0
+        self._twin = None
+        self._weights = weights if (dtype == 'f16x3' and self.on_range_event == 'f32') else None
+        self.class_specific_filter = class_specific_filter
         self.osf = bool(orientation_specific_filter)     # per-orientation NMS (filter_detections.py:84-98), gpp_detect_osf_f32
         self.nms = bool(nms)
         self.name = name
@@ -198,6 +213,8 @@ class RetinaNet3D(object):
         self._load_tune_cache()
         self._upload(weights)
         self.tag_names = []          # filled by the plan builder: names of event-tagged ops
+        if dtype == 'f16x3' and self.on_range_event != 'ignore':
+            self._range_seen = self.x3_range_events()
 
     # ------------------------------------------------------------------ weights
     def _upload(self, weights):
@@ -729,6 +746,8 @@ class RetinaNet3D(object):
         counter is per device, shared by every f16x3 model on it).  Zero = the type's range altered nothing.  Synchronises. """
         n = ctypes.c_uint64(0)
         hip.check(hip.lib().gpp_x3_range_events(ctypes.byref(n), int(bool(reset))), 'gpp_x3_range_events')
+        if reset:
+            self._range_seen = 0
         return int(n.value)
 
     def plan_for(self, B, H, Wd, n_planes, planes_batched):
@@ -781,7 +800,79 @@ class RetinaNet3D(object):
         orientations (B,100) i32, keypoints (B,100,4,3) f32, keyplanes (B,100,1,4) f32, residuals (B,100) f32. """
         plan = self.stage_inputs(inputs)
         self.run_plan(plan)
-        return [t.cpu().numpy() for t in self.outputs(plan)]
+        return self.fetch(plan)
+
+    def fetch(self, plan, packed=None):
+        """ the 8 result arrays of the plan's last run as writable NumPy arrays (synchronises).  packed (default; GPP_FETCH=separate for
+        the other form): ONE launch packs them into a (B, 100, 35) float32 tensor (gpp_pack_detections; labels / orientations are small
+        integers: exact) and ONE copy brings it to the host, instead of eight blocking copies of 0.4 - 4.8 KB per image -- the same bytes
+        (tests/test_network_gpu.py), 8 -> 1 host round trips inside the bracket the reference times (bin/run_network.py:108-111). """
+        if packed is None:
+            packed = os.environ.get('GPP_FETCH', 'packed') != 'separate'
+        watch = self.watches_range()
+        if packed:
+            outs, count = self.unpack_with_range(self.pack_with_range(plan).cpu().numpy(), plan.shape[0])
+        else:
+            outs = [t.cpu().numpy() for t in self.outputs(plan)]
+            count = int(self.range_snapshot().cpu().view(self.torch.int64).item()) if watch else 0
+        if watch and count != self._range_seen:
+            self._range_seen = count
+            return self._range_event([plan.images, plan.P_inv, plan.planes], 'predict_on_batch')
+        return outs
+
+    # ------------------------------------------------------------------ f16x3: the half range, watched
+    def watches_range(self):
+        return self.dtype == 'f16x3' and self.on_range_event != 'ignore'
+
+    def range_snapshot(self, dst=None):
+        """ enqueue a copy of the device's range-event counter (its value at this point of the current stream) into two float32 words
+        of device memory (gpp_x3_range_snapshot); no synchronisation """
+        if dst is None:
+            dst = self.torch.empty((2,), dtype=self.torch.float32, device=self.device)
+        hip.check(hip.lib().gpp_x3_range_snapshot(ctypes.c_void_p(dst.data_ptr()), hip.stream_ptr()), 'gpp_x3_range_snapshot')
+        return dst
+
+    def pack_with_range(self, plan, out=None):
+        """ the results of the plan's last run as ONE flat float32 device buffer: B x 100 x 35 packed detections (gpp_pack_detections)
+        followed by the 8 bytes of the range-event counter as the stream saw it behind them -- one copy brings both to the host """
+        from ..utils import distributed as D
+        torch = self.torch
+        outs = self.outputs(plan)
+        B, Dn = int(outs[0].shape[0]), int(outs[0].shape[1])
+        n = B * Dn * D.PACK_WIDTH
+        if out is None:
+            out = torch.empty((n + 2,), dtype=torch.float32, device=self.device)
+        hip.check(hip.lib().gpp_pack_detections(*([hip.ptr(o) for o in outs] + [B, Dn, ctypes.c_void_p(out.data_ptr()), hip.stream_ptr()])),
+                  'gpp_pack_detections')
+        if self.watches_range():
+            self.range_snapshot(out[n:])
+        return out
+
+    @staticmethod
+    def unpack_with_range(flat, B):
+        """ host side of pack_with_range: (the 8 NumPy result arrays, the counter value) """
+        from ..utils import distributed as D
+        flat = np.ascontiguousarray(flat)
+        n = flat.size - 2
+        return D.unpack_outputs(flat[:n].reshape(B, n // (B * D.PACK_WIDTH), D.PACK_WIDTH)), int(flat[n:].view(np.uint64)[0])
+
+    def _range_event(self, device_inputs, what):
+        """ an activation of the call just fetched left the half range: its result is not the reference's.  device_inputs = the call's
+        [images, P_inv, planes] still in HBM. """
+        self.range_fallbacks += 1
+        if self.on_range_event == 'raise':
+            raise hip.GppError('{}: an activation left the IEEE-half range of dtype=\'f16x3\' (finite beyond +-65504, inf or NaN; '
+                               'gpp_x3_range_events): the result would not be the reference\'s -- load the model with dtype=\'f32\' '
+                               'or on_range_event=\'f32\''.format(what))
+        if self._twin is None:
+            self._twin = RetinaNet3D(self._weights, backbone_name=self.backbone_name, dtype='f32', nms=self.nms,
+                                     class_specific_filter=self.class_specific_filter, orientation_specific_filter=self.osf,
+                                     name=self.name + '-f32-twin')
+        if what == 'predict_on_frames':          # device_inputs = [frames uint8, P_inv, planes]: preprocessing included
+            return self._twin.predict_on_frames(*device_inputs)[0]
+        plan = self._twin.stage_inputs(device_inputs)
+        self._twin.run_plan(plan)
+        return self._twin.fetch(plan)
 
     def stage_inputs(self, inputs):
         """ Copy [images, P_inv, planes] into the plan's device buffers; returns the plan. """
@@ -806,7 +897,19 @@ class RetinaNet3D(object):
             else:
                 dst.copy_(torch.as_tensor(np.ascontiguousarray(src, dtype=np.float32)), non_blocking=True)
 
-        put(plan.images, images)
+        if not isinstance(images, torch.Tensor) and os.environ.get('GPP_UPLOAD', 'pinned') == 'pinned':
+            # host frames go through a page-locked staging buffer of the plan: one memcpy on the host, then a DMA the stream orders in
+            # front of the plan (a copy from pageable memory is staged by the runtime chunk by chunk and blocks the caller meanwhile)
+            if getattr(plan, 'host_images', None) is None:
+                plan.host_images = torch.empty(tuple(plan.images.shape), dtype=torch.float32, pin_memory=True)
+                plan.host_images_free = torch.cuda.Event()
+            else:
+                plan.host_images_free.synchronize()          # the previous upload out of this buffer has left it
+            np.copyto(plan.host_images.numpy(), images, casting='same_kind')
+            plan.images.copy_(plan.host_images, non_blocking=True)
+            plan.host_images_free.record()
+        else:
+            put(plan.images, images)
         put(plan.P_inv, P_inv)
         put(plan.planes, planes)
         return plan
@@ -856,7 +959,7 @@ class RetinaNet3D(object):
         have been computed for that scale (utils.image.compute_resize_scale). """
         plan, scale = self.stage_frames(frames_u8, P_inv, planes)
         self.run_plan(plan)
-        return [t.cpu().numpy() for t in self.outputs(plan)], scale
+        return self.fetch(plan), scale
 
     # Keras-style conveniences used by the reference's scripts
     def predict(self, inputs, batch_size=None, verbose=0):

@@ -96,8 +96,12 @@ SYN_DIM_OUT_GAIN = 0.18       # dimension deltas ~ N(0, 1)
 SYN_BACKBONE_OUT_SCALE = {'resnet50': 1.0, 'resnet101': 0.676, 'resnet152': 0.52}
 
 
-def synthetic_weights(backbone='resnet50', seed=1234):
-    """ Seeded random weights with the exact architecture of `backbone` + FPN + heads. """
+def synthetic_weights(backbone='resnet50', seed=1234, family='he'):
+    """ Seeded random weights with the exact architecture of `backbone` + FPN + heads.
+    family 'he': He-normal kernels, BatchNormalization close to the identity (every activation O(1)).
+    family 'trained': the same draw re-parameterised the way a trained checkpoint looks (trained_like below). """
+    if family not in ('he', 'trained'):
+        raise ValueError("family must be 'he' or 'trained', got {!r}".format(family))
     w = {}
     stage_blocks = {str(stage + 2): n for stage, n in enumerate(BLOCKS[backbone])}
     for conv, bn, kh, kw, cin, cout, _ in backbone_layers(backbone):
@@ -130,7 +134,60 @@ def synthetic_weights(backbone='resnet50', seed=1234):
             w[name + '/bias'] = np.zeros((cout,), np.float32)
     # initializers.PriorProbability(0.01): bias = -log((1 - p) / p)   (initializers.py:23-39)
     w['pyramid_classification/bias'][:] = np.float32(-np.log((1.0 - 0.01) / 0.01))
+    if family == 'trained':
+        trained_like(w, backbone, seed)
     return w
+
+
+TRAINED_STAGE_GAIN = (1.0, 4.0, 16.0, 64.0)       # scale of the residual stream in res2 .. res5 of the 'trained' family
+TRAINED_CHANNEL_SPREAD = (1e-2, 1e1)              # per-channel scale of the inner bottleneck maps, log-uniform
+TRAINED_DEAD_FRACTION = 0.02                      # channels of the inner maps that never fire
+
+
+def trained_like(w, backbone, seed):
+    """ Re-parameterise a synthetic draw IN PLACE so that its activation statistics look like a trained checkpoint's rather than like an
+    initialisation (the reference's operating point is a trained KITTI model, README.md:75; none exists offline):
+      * every channel of the two inner maps of a bottleneck (branch2a, branch2b outputs) gets its own scale, log-uniform over
+        1e-2 .. 1e1 (BatchNormalization gamma and beta x s_c, the consuming kernel's input channel / s_c): three decades between the
+        channels of one stored map -- what a narrow arithmetic type sees as small and large values side by side;
+      * 2 % of those channels are dead (gamma = 0, beta < 0: zero after the ReLU);
+      * the residual stream grows stage by stage (x 1, 4, 16, 64 for res2 .. res5: gamma and beta of branch2c / branch1 x G, the
+        kernels that read the stream -- the next branch2a / branch1, C3 / C4 / C5_reduced, P6 -- / G).
+    ReLU commutes with a positive scale, so the function the network computes is the base draw's up to rounding: the calibration of
+    the synthetic head outputs (about a thousand anchors above the score threshold per frame) carries over. """
+    r = _rng(seed, 'trained_like')
+    lo, hi = np.log(TRAINED_CHANNEL_SPREAD[0]), np.log(TRAINED_CHANNEL_SPREAD[1])
+    f32 = np.float32
+    for stage, n_blocks in enumerate(BLOCKS[backbone]):
+        G = f32(TRAINED_STAGE_GAIN[stage])
+        for block in range(n_blocks):
+            nm = block_name(backbone, stage, block)
+            g_in = f32(TRAINED_STAGE_GAIN[stage - 1]) if (block == 0 and stage > 0) else (f32(1.0) if block == 0 else G)
+            for producer, consumer in (('2a', '2b'), ('2b', '2c')):
+                bn, conv = 'bn{}_branch{}'.format(nm, producer), 'res{}_branch{}'.format(nm, consumer)
+                c = w[bn + '/gamma'].shape[0]
+                s = np.exp(r.uniform(lo, hi, c)).astype(f32)
+                dead = r.random(c) < TRAINED_DEAD_FRACTION
+                w[bn + '/gamma'] = np.where(dead, f32(0.0), w[bn + '/gamma'] * s).astype(f32)
+                w[bn + '/beta'] = np.where(dead, f32(-0.05), w[bn + '/beta'] * s).astype(f32)
+                w[conv + '/kernel'] = (w[conv + '/kernel'] / s[None, None, :, None]).astype(f32)
+            readers = ['res{}_branch2a'.format(nm)] + (['res{}_branch1'.format(nm)] if block == 0 else [])
+            for conv in readers:
+                w[conv + '/kernel'] = (w[conv + '/kernel'] / g_in).astype(f32)
+            for bn in ['bn{}_branch2c'.format(nm)] + (['bn{}_branch1'.format(nm)] if block == 0 else []):
+                w[bn + '/gamma'] = (w[bn + '/gamma'] * G).astype(f32)
+                w[bn + '/beta'] = (w[bn + '/beta'] * G).astype(f32)
+    for conv, stage in (('C3_reduced', 1), ('C4_reduced', 2), ('C5_reduced', 3), ('P6', 3)):
+        w[conv + '/kernel'] = (w[conv + '/kernel'] / f32(TRAINED_STAGE_GAIN[stage])).astype(f32)
+    return w
+
+
+def parse_synthetic(spec):
+    """ 'synthetic', 'synthetic:<seed>', 'synthetic:<seed>:trained' (also with a trailing '.h5': bin/run_network.py strips three
+    characters of the model path) -> (seed, family) """
+    import re
+    m = re.match(r'synthetic(?::(\d+))?(?::(he|trained))?', spec)
+    return (int(m.group(1)) if m and m.group(1) else 1234), (m.group(2) if m and m.group(2) else 'he')
 
 
 def expected_arrays(backbone):

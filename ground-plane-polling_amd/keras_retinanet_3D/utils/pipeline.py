@@ -9,7 +9,6 @@ the same loop.  Results are bit-identical to model.predict_on_frames called batc
 
 import numpy as np
 
-from ..backend import hip
 from . import distributed as D
 
 
@@ -60,8 +59,10 @@ class FramePipeline(object):
                 'd_frames': torch.empty(tuple(frames.shape), dtype=torch.uint8, device=dev),
                 'd_pinv': torch.empty(tuple(P_inv.shape), dtype=torch.float32, device=dev),
                 'd_planes': torch.empty(tuple(planes.shape), dtype=torch.float32, device=dev),
-                'd_packed': torch.empty((B, 100, D.PACK_WIDTH), dtype=torch.float32, device=dev),
-                'h_packed': torch.empty((B, 100, D.PACK_WIDTH), dtype=torch.float32).pin_memory() if (self.pinned or self.inline) else None,
+                # B x 100 x 35 packed detections + the 8 bytes of the f16x3 range-event counter behind them (model.pack_with_range)
+                'd_packed': torch.empty((B * 100 * D.PACK_WIDTH + 2,), dtype=torch.float32, device=dev),
+                'h_packed': torch.empty((B * 100 * D.PACK_WIDTH + 2,), dtype=torch.float32).pin_memory() if (self.pinned or self.inline) else None,
+                'B': B,
                 'uploaded': torch.cuda.Event(), 'consumed': torch.cuda.Event(), 'done': torch.cuda.Event(),
                 'downloaded': torch.cuda.Event(),
             })
@@ -90,10 +91,8 @@ class FramePipeline(object):
         if self.graph and getattr(plan, 'graph', None) is None:
             self.model.capture(plan)
         self.model.run_plan(plan)
-        outs = self.model.outputs(plan)                            # the plan's buffers: the next batch overwrites them,
-        hip.check(hip.lib().gpp_pack_detections(*([hip.ptr(o) for o in outs] +     # so the results leave through the slot
-                                                  [int(outs[0].shape[0]), int(outs[0].shape[1]), hip.ptr(slot['d_packed']),
-                                                   hip.stream_ptr()])), 'gpp_pack_detections')
+        self.model.pack_with_range(plan, slot['d_packed'])         # the plan's buffers are overwritten by the next batch: the results
+        #                                                            (and the f16x3 range counter as of this batch) leave through the slot
         slot['done'].record(cur)
         if self.inline:
             slot['h_packed'].copy_(slot['d_packed'], non_blocking=True)
@@ -139,11 +138,17 @@ class FramePipeline(object):
             yield self._collect(pending.pop(0))
 
     def _collect(self, slot):
-        if self.inline:
+        if self.inline or self.pinned:
             slot['downloaded'].synchronize()                        # this batch's copy only: later batches keep running
-            return D.unpack_outputs(slot['h_packed'].numpy().copy()), slot['scale']
-        if not self.pinned:
+            flat = slot['h_packed'].numpy().copy()
+        else:
             slot['done'].synchronize()
-            return D.unpack_outputs(slot['d_packed'].cpu().numpy()), slot['scale']
-        slot['downloaded'].synchronize()
-        return D.unpack_outputs(slot['h_packed'].numpy().copy()), slot['scale']
+            flat = slot['d_packed'].cpu().numpy()
+        outs, count = self.model.unpack_with_range(flat, slot['B'])
+        m = self.model
+        if m.watches_range() and count != m._range_seen:
+            # an activation of this batch (or of one still in flight behind it: the counter is the device's) left the half range:
+            # the batch is run again at float32 from the slot's own inputs, which nothing has overwritten yet (on_range_event)
+            m._range_seen = count
+            outs = m._range_event([slot['d_frames'], slot['d_pinv'], slot['d_planes']], 'predict_on_frames')
+        return outs, slot['scale']

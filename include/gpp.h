@@ -223,6 +223,13 @@ int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1
    means no activation of that run was altered by the type's range (models/retinanet.py: model.x3_range_events()). */
 int gpp_x3_range_events(uint64_t* host_count, int reset);
 
+/* The same counter WITHOUT a synchronisation: one tiny launch on `stream` copies the counter's value at that point of the stream
+   into *device_count (8 bytes of device memory, or of page-locked host memory the device can write).  Enqueued behind a plan run,
+   the value tells -- once the stream has reached it -- whether an activation of that run (or of any earlier one since the last
+   reset) left the half range; models/retinanet.py reads it with the results it fetches anyway and re-runs an affected call at
+   float32 (`on_range_event`), so that a clamped activation is never returned as a plausible wrong answer. */
+int gpp_x3_range_snapshot(uint64_t* device_count, void* stream);
+
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
 

@@ -43,3 +43,26 @@ def test_a_failing_rank_ends_the_job_with_its_exit_code():
     out = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--dry-launch', '--batch', '0'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          universal_newlines=True, timeout=300, cwd=ROOT, env=_env())
     assert out.returncode != 0
+
+
+def test_gpus_8_launches_eight_ranks_and_prints_the_diagnosis_block():
+    # the shape of the driver's scaling run (N = 8), rehearsed on gloo: eight children, one stdout line, the per-rank diagnosis keys of a real line
+    out = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--dry-launch', '--batch', '8'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=600, cwd=ROOT, env=_env(OMP_NUM_THREADS='1'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['world_size'] == 8 and rec['n_gpus'] == 8 and rec['gathered_images_per_step'] == 64 and rec['gather_correct'] is True
+    diag = rec['multi_gpu_diagnosis']
+    assert diag['ranks'] == 8
+    for key in ('ms_per_step', 'gather_wait_ms_per_step', 'sclk_mhz_median', 'power_w_median', 'power_cap_w', 'model_load_s', 'plan_build_and_tune_s'):
+        assert set(diag[key]) == {'per_rank', 'min', 'median', 'max'} and len(diag[key]['per_rank']) == 8
+    assert diag['sclk_mhz_median']['per_rank'] == [float(r) for r in range(8)] and diag['sclk_mhz_median']['median'] == 3.5
+    assert diag['power_cap_w']['per_rank'] == [None] * 8 and diag['power_cap_w']['max'] is None       # a figure no rank could read stays empty
+
+
+def test_a_failing_rank_of_eight_ends_the_job():
+    out = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--dry-launch', '--batch', '0'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=600, cwd=ROOT, env=_env(OMP_NUM_THREADS='1'))
+    assert out.returncode != 0 and out.stdout.strip() == ''

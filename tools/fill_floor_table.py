@@ -6,7 +6,7 @@ that gets the most workgroups, the MFMA floor, the HBM floor (round 4: the layer
 output map, weights -- at 6.3 TB/s; the float32-sized maps of the x3 types make the 1x1 layers of res2 / res3 and the expand layers
 HBM-bound, not fill-bound; a plain elementwise kernel reaches 5.9 TB/s hot and 4.3 - 4.9 TB/s cold on the same boxes,
 tools/hbm_layers.py) and the measured launch time hot (back to back) and cold (600 MB rewritten in between, as inside the network).
-    python tools/fill_floor_table.py [dtype] [backbone]              (on the GPU box) """
+    python tools/fill_floor_table.py [dtype] [backbone] [batch = 8]              (on the GPU box) """
 import ctypes
 import os
 os.environ.setdefault('GPP_HALF_LANES', '')          # one launch per layer (whole batch)
@@ -25,7 +25,7 @@ dtype = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 backbone = sys.argv[2] if len(sys.argv) > 2 else 'resnet50'
 HBM_TBPS = 6.3
 FILL_GBPS, PEAK = 56.0, {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3, 'f16x3': 2500.0 / 3}[dtype]
-B, H, W = 8, 402, 1333
+B, H, W = (int(sys.argv[3]) if len(sys.argv) > 3 else 8), 402, 1333
 model = models.load_model('synthetic:1234', backbone_name=backbone, dtype=dtype)
 plan = model.plan_for(B, H, W, 1000, True)
 model.run_plan(plan)
