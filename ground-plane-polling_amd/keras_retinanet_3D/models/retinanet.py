@@ -520,15 +520,22 @@ class RetinaNet3D(object):
             plan.regression_dim, dim_o = pyramid(36, torch.float32)
             self._conv(plan, 'pyramid_regression_dim', dim_t, dim_o, 3, pad=(1, 1), out_f32=True, lane=l_dim)
 
+        # GPP_CLS_LANE (default: on for B <= 2): the classification tower (+ the candidate pass behind it) on side lane 2 BESIDE the regression
+        # tower instead of in front of it.  At batch 1 a tower launch fields 0.9 - 1.9 rounds of workgroups of one wavefront per SIMD: two
+        # independent chains in flight fill the other half of every SIMD (measured: profiles/r5/b1_plan_variants.json).  `pyramid_regression_ops`
+        # joins the lane, so the selection that follows sees the candidate keys; at batch 8 every launch fills the chip on its own (off).
+        cls_lane = 2 if (overlap and os.environ.get('GPP_CLS_LANE', '1' if B <= 2 else '0') != '0') else 0
+        plan.side_lanes['cls_tower'] = bool(cls_lane)
+
         def cls_tower():
-            cls_t = tower('pyramid_classification', 256, slice_of(wide_maps, 512, 256), lane=l_cls)
+            cls_t = tower('pyramid_classification', 256, slice_of(wide_maps, 512, 256), lane=l_cls or cls_lane)
             plan.cls_logits, cls_o = pyramid(96, torch.float32)
-            self._conv(plan, 'pyramid_classification', cls_t, cls_o, 3, pad=(1, 1), out_f32=True, lane=l_cls)
+            self._conv(plan, 'pyramid_classification', cls_t, cls_o, 3, pad=(1, 1), out_f32=True, lane=l_cls or cls_lane)
 
         def reg_tower():
             reg_t = tower('pyramid_regression', 512, slice_of(wide_maps, 0, 512), tag=1)
             plan.regression, reg_o = pyramid(144, torch.float32)
-            self._conv(plan, 'pyramid_regression_ops', reg_t, reg_o, 3, pad=(1, 1), out_f32=True)
+            self._conv(plan, 'pyramid_regression_ops', reg_t, reg_o, 3, pad=(1, 1), out_f32=True, join=bool(cls_lane))
 
         detect_at = {}
         if overlap:
@@ -580,7 +587,7 @@ class RetinaNet3D(object):
             plan.lanes.insert(at, (1 << 8) | OP_SYNC)
             at = detect_at['candidates']
             plan.ops.insert(at, (OP_DETECT_CANDIDATES, 0, dd, 'filtered_detections/candidates', 0.0))
-            plan.lanes.insert(at, 1 << 8)
+            plan.lanes.insert(at, (cls_lane or 1) << 8)             # behind the classification tower: on its lane when it has one
             plan.add(OP_DETECT_EMIT, dd, 'filtered_detections', join=True)
         else:
             plan.add(OP_DETECT_OSF if self.osf else OP_DETECT, dd, 'filtered_detections', join=True)
@@ -897,9 +904,11 @@ class RetinaNet3D(object):
             else:
                 dst.copy_(torch.as_tensor(np.ascontiguousarray(src, dtype=np.float32)), non_blocking=True)
 
-        if not isinstance(images, torch.Tensor) and os.environ.get('GPP_UPLOAD', 'pinned') == 'pinned':
-            # host frames go through a page-locked staging buffer of the plan: one memcpy on the host, then a DMA the stream orders in
-            # front of the plan (a copy from pageable memory is staged by the runtime chunk by chunk and blocks the caller meanwhile)
+        if not isinstance(images, torch.Tensor) and os.environ.get('GPP_UPLOAD', 'pageable') == 'pinned':
+            # GPP_UPLOAD=pinned: host frames go through a page-locked staging buffer of the plan (one memcpy on the host, then a DMA).
+            # Measured at batch 1 (tools/b1_latency.py --host-variants, profiles/r5/b1_latency.json): 0.37 ms for the 6.4 MB float32 frame
+            # against 0.16 - 0.17 ms for the runtime's own staged copy from pageable memory -- the host memcpy costs more than it saves,
+            # so the plain copy is the default
             if getattr(plan, 'host_images', None) is None:
                 plan.host_images = torch.empty(tuple(plan.images.shape), dtype=torch.float32, pin_memory=True)
                 plan.host_images_free = torch.cuda.Event()

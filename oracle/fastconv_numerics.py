@@ -229,8 +229,19 @@ def main():
     if args.only:
         runs = [r for r in runs if any(s in r[0] for s in args.only.split(';'))]
     report = {'config': args.config, 'frames': int(n), 'device': args.device, 'rows': {}}
+
+    def print_row(name, r):
+        d = r['distribution']
+        print(' | '.join(CD.fmt(v) for v in (name, '{}/{}'.format(r['common'], r['union']), r['set_differences_unexplained'], r['set_differences_at_a_tie'],
+                                            '{}/{}'.format(r['same_plane'], r['common']), r['plane_differences_with_equal_inputs'],
+                                            d.get('n_within_100m'), d.get('corner_p50', 0.0), d.get('corner_p99', 0.0), d.get('corner_max', 0.0),
+                                            d.get('corner_above_1e-3', 0), d.get('scaled_beyond_max', 0.0), r['meets_reference_bars'])), flush=True)
+
     if full:
+        print('{}: {} frames against tests/golden/fullsize_{}_f64.npz; bars: utils/ledger.REFERENCE_BARS, unchanged'.format(args.config, n, args.config))
+        print(' | '.join(('run', 'dets', 'unexplained set diff', 'ties', 'plane', 'flips', 'n<=100m', 'p50', 'p99', 'max', '>1e-3', 'scaled max >100m', 'bars met')))
         report['rows']['float32 CPU oracle vs f64 oracle (float32 itself)'] = CD.compare(g64, g32, ledger)
+        print_row('float32 CPU oracle vs f64 oracle (float32 itself)', report['rows']['float32 CPU oracle vs f64 oracle (float32 itself)'])
     for title, modes in runs:
         net = EmuNet(weights, backbone, modes, args.device)
         outs, aidx, pidx = {k: [] for k in range(8)}, [], []
@@ -254,21 +265,12 @@ def main():
             row['winograd_layers'] = sorted(nm for nm, m in net.used.items() if m != 'x3')
             row['seconds'] = round(time.time() - t0, 1)
             report['rows'][title] = row
+            print_row(title, row)
+            if args.json:
+                with open(args.json, 'w') as f:
+                    json.dump(report, f, indent=1, default=float)
         else:
             print(title, 'detections', int((got[0][2] > 0.05).sum()), 'planes', got[2][0][:5])
-    if full:
-        print('{}: {} frames against tests/golden/fullsize_{}_f64.npz; bars: utils/ledger.REFERENCE_BARS, unchanged'.format(args.config, n, args.config))
-        head = ('run', 'dets', 'unexplained set diff', 'ties', 'plane', 'flips', 'n<=100m', 'p50', 'p99', 'max', '>1e-3', 'scaled max >100m', 'bars met')
-        print(' | '.join(head))
-        for name, r in report['rows'].items():
-            d = r['distribution']
-            print(' | '.join(CD.fmt(v) for v in (name, '{}/{}'.format(r['common'], r['union']), r['set_differences_unexplained'], r['set_differences_at_a_tie'],
-                                                '{}/{}'.format(r['same_plane'], r['common']), r['plane_differences_with_equal_inputs'],
-                                                d.get('n_within_100m'), d.get('corner_p50', 0.0), d.get('corner_p99', 0.0), d.get('corner_max', 0.0),
-                                                d.get('corner_above_1e-3', 0), d.get('scaled_beyond_max', 0.0), r['meets_reference_bars'])))
-        if args.json:
-            with open(args.json, 'w') as f:
-                json.dump(report, f, indent=1, default=float)
 
 
 if __name__ == '__main__':

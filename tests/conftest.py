@@ -9,8 +9,61 @@ for p in (os.path.join(ROOT, 'ground-plane-polling_amd'), ROOT):
         sys.path.insert(0, p)
 
 
+GPU_SUITE_BUDGET_S = 600.0      # the driver gives `pytest -m gpu` 900 s on its box; the default selection has to fit with a margin
+
+
+def pytest_addoption(parser):
+    parser.addoption('--run-slow', action='store_true', default=False,
+                     help='also run the soak-style parametrisations marked `slow` (tools/collect_r5.sh does; the default -m gpu run does not)')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: soak-style parametrisation (preemption loops, the fixture frames beyond the first 16, the less used '
+                                       'types and plan variants): deselected unless --run-slow or -m names `slow`')
+    config._gpp_durations = []
+    config._gpp_t0 = None
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption('--run-slow') or 'slow' in (config.getoption('-m') or ''):
+        return
+    keep, drop = [], []
+    for item in items:
+        (drop if item.get_closest_marker('slow') else keep).append(item)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
+
+
+def pytest_sessionstart(session):
+    import time
+    session.config._gpp_t0 = time.time()
+
+
+def pytest_runtest_logreport(report):
+    if report.when == 'call' or (report.when == 'setup' and report.duration > 1.0):
+        _DURATIONS.append((report.duration, report.nodeid, report.when))
+
+
+_DURATIONS = []
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """ the default GPU selection must stay inside its budget: a suite that outgrows the driver's step limit turns every parity row red """
+    import time
+    marker = session.config.getoption('-m') or ''
+    if 'gpu' not in marker or 'not gpu' in marker or session.config.getoption('--run-slow') or 'slow' in marker:
+        return
+    if len(_DURATIONS) < 200:                         # a hand-picked subset, not the suite
+        return
+    elapsed = time.time() - (session.config._gpp_t0 or time.time())
+    if elapsed > GPU_SUITE_BUDGET_S:
+        worst = sorted(_DURATIONS, reverse=True)[:10]
+        print('\nGPU suite took {:.0f} s, budget {:.0f} s.  Ten slowest:'.format(elapsed, GPU_SUITE_BUDGET_S))
+        for d, node, when in worst:
+            print('  {:7.1f} s  {}  ({})'.format(d, node, when))
+        session.exitstatus = 1
 
 
 @pytest.fixture(scope='session', autouse=True)

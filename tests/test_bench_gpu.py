@@ -52,6 +52,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cfg['gpu_decode_polling_replay_bit_exact'] is True and cfg['resident_batches_rotated'] >= 4
     assert cfg['host_fed_streaming_images_per_s'] > 0.5 * rec['value'] and cfg['rccl_world_size'] == 1
     assert roof['library'].startswith('gpp-hip') and 'src:' in roof['library']
+    # round 5: the line's own error bar, and the reference's own timer (one synchronous batch-1 call, bin/run_network.py:108-111)
+    assert len(cfg['repeat_images_per_s']) == 3 and all(v > 400.0 for v in cfg['repeat_images_per_s']) and len(roof['frac_per_repeat']) == 3
+    b1 = cfg['b1']
+    assert 0.5 < b1['plan_only_ms_median'] < b1['sync_ms_median'] < 20.0 and b1['sync_ms_p90'] >= b1['sync_ms_median'] and b1['detections_last_call'] > 0
+    assert set(b1['stages_ms']) == {'stem+backbone', 'fpn', 'heads+selection', 'emit+polling'} and b1['floor_ms'] < b1['plan_only_ms_median']
 
 
 @pytest.mark.gpu

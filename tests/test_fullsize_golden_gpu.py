@@ -66,12 +66,15 @@ def run_hip(config, dtype, weights='synthetic:1234', frames=None):
     return ([np.concatenate([o[k] for o in outs]) for k in range(8)], np.concatenate(aidx), np.concatenate(pidx)), events
 
 
+@pytest.mark.parametrize('frames', [16, pytest.param(None, marks=pytest.mark.slow)], ids=['first16', 'all'])
 @pytest.mark.parametrize('dtype', ['f32', 'f16x3'])
 @pytest.mark.parametrize('config', list(CONFIGS))
-def test_hip_path_against_the_cpu_oracle_fixtures(config, dtype):
-    g64, g32 = CD.load_golden(config, 'f64'), CD.load_golden(config, 'f32')
-    assert g64[1].shape[0] == CONFIGS[config][0]
-    got, events = run_hip(config, dtype)
+def test_hip_path_against_the_cpu_oracle_fixtures(config, dtype, frames):
+    """ the default GPU run compares the first 16 frames of every fixture; all 64 / 32 / 32 run under --run-slow (tools/collect_r5.sh) """
+    g64, g32 = CD.load_golden(config, 'f64', frames), CD.load_golden(config, 'f32', frames)
+    n_frames = frames or CONFIGS[config][0]
+    assert g64[1].shape[0] == n_frames
+    got, events = run_hip(config, dtype, frames=frames)
     exact = CD.compare(g64, got, ledger)
     pair = CD.compare(g32, got, ledger)
     floor = CD.compare(g64, g32, ledger)                              # float32 itself (the CPU oracle) against the exact value
@@ -80,10 +83,10 @@ def test_hip_path_against_the_cpu_oracle_fixtures(config, dtype):
           'float32 CPU oracle vs f64: p50 {:.2e} p99 {:.2e} max {:.2e}'.format(
               config, dtype, exact['common'], exact['union'], exact['set_differences_at_a_tie'], de['corner_p50'], de['corner_p99'],
               de['corner_max'], exact['max_corner_dev_scaled_beyond_100m'], df['corner_p50'], df['corner_p99'], df['corner_max']))
-    n = 100 * CONFIGS[config][0]
+    n = 100 * n_frames
     assert exact['detections_ref'] == exact['detections'] == n
     # the same detections (a difference must be a tie at the cut: the float64 fixture shows how close the 100th and 101st are)
-    assert exact['set_differences_unexplained'] == 0 and exact['set_differences'] <= 2 * CONFIGS[config][0] // 4, exact
+    assert exact['set_differences_unexplained'] == 0 and exact['set_differences'] <= 2 * n_frames // 4, exact
     for s in CD.set_differences(g64, got, g64[3]):
         assert s['gap_at_the_cut'] <= ledger.TIE_EPS, s
     # the same orientation for every detection both report, and the same plane -- up to ledger.PLANE_FLIPS_PER_1000 detections whose polling
@@ -94,7 +97,7 @@ def test_hip_path_against_the_cpu_oracle_fixtures(config, dtype):
         exact['plane_differences'], flips, floor['plane_differences']))
     assert exact['same_orientation'] == exact['common'] and exact['same_plane'] + flips == exact['common'], exact
     assert flips <= ledger.PLANE_FLIPS_PER_1000 * -(-exact['common'] // 1000), exact
-    assert floor['plane_differences'] == floor['plane_differences_with_equal_inputs'] == (1 if config == 'resnet152_22k' else 0)
+    assert floor['plane_differences'] == floor['plane_differences_with_equal_inputs'] == (1 if config == 'resnet152_22k' else 0)      # (frame 9)
     # 3-D corners
     bar = 1.0e-3 if dtype == 'f16x3' else 1.5e-3
     assert exact['same_plane_within_100m'] >= 0.8 * exact['common']
@@ -131,3 +134,26 @@ def test_the_bars_hold_on_weight_draws_they_were_not_fitted_on(config, draw):
     assert ledger.meets_reference_bars(pair, pair=True), pair
     for key in ('corner_p50', 'corner_p90', 'corner_p99'):            # as close to the exact value as float32 itself is
         assert de[key] <= 1.25 * df[key], (key, de[key], df[key])
+
+
+def test_config_1_shape_one_frame_ten_planes_against_the_oracle(oracle_lib):
+    """ BASELINE.json configs[0]: ONE 1242x375 frame (402x1333 network input), resnet50, road_planes_database_10 -- the call
+    bin/run_network.py:108-111 times -- through the HIP path at batch 1 in the headline type, against the float64 oracle's detections of
+    the same frame (the committed fixture) polled by oracle/polling.c over the 10-plane database. """
+    import helpers
+    g64 = CD.load_golden('resnet50_1k', 'f64', 2)
+    planes = synthetic.load_plane_database('10').astype(np.float32)
+    _, P_inv = synthetic.synthetic_calibration()
+    P_inv = P_inv[None].astype(np.float32)
+    model = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='f16x3')
+    model.x3_range_events(reset=True)
+    for frame in (0, 1):
+        det = [g64[0][k][frame:frame + 1] for k in range(5)]
+        kp, kpl, res, idx = helpers.c_oracle_poll(oracle_lib, det[0], det[1], det[4], P_inv, planes[None])
+        out = model.predict_on_batch([synthetic.synthetic_network_input([frame]), P_inv, planes[None]])
+        plan = model.plan_for(1, 402, 1333, 10, True)
+        assert [o.shape for o in out] == [(1, 100, 12), (1, 100, 3), (1, 100), (1, 100), (1, 100), (1, 100, 4, 3), (1, 100, 1, 4), (1, 100)]
+        led = ledger.parity_ledger(det + [kp, kpl, res], g64[1][frame:frame + 1], idx, out, plan.anchor_index.cpu().numpy(), plan.best_index.cpu().numpy())
+        assert led['common'] == led['union'] == 100 and ledger.meets_reference_bars(led), led
+        assert 0 <= int(plan.best_index.max()) < 10
+    assert model.x3_range_events() == 0 and model.range_fallbacks == 0

@@ -46,7 +46,7 @@ def _heads(plan, batch):
             'classification_logits': plan.cls_logits.cpu().numpy().reshape(batch, -1, 8)}
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'f16', 'f32', 'bf16x3', 'f16x3'])
+@pytest.mark.parametrize('dtype', ['bf16', 'f32', 'f16x3', pytest.param('f16', marks=pytest.mark.slow), pytest.param('bf16x3', marks=pytest.mark.slow)])
 def test_every_layer_at_402x1333(dtype, monkeypatch):
     check_every_layer('resnet50', dtype, '0', 2, H, WD, monkeypatch)
 

@@ -203,7 +203,7 @@ def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
         return outs, plan
 
     lanes, plan = run(4)
-    assert plan.side_lanes == {'fpn': True, 'branch1': True, 'p4': True, 'half_batch_stages': [1, 2, 3]}
+    assert plan.side_lanes == {'fpn': True, 'branch1': True, 'p4': True, 'half_batch_stages': [1, 2, 3], 'cls_tower': False}
     names = [op[3] for op in plan.ops]
     assert names.index('res2a_branch1') < names.index('res2a_branch2a')          # forked before the chain it runs beside
     assert names.count('res4b_branch2b') == 2                                    # one launch per half batch
@@ -211,7 +211,7 @@ def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
     monkeypatch.setenv('GPP_FPN_LANES', '0')
     monkeypatch.setenv('GPP_HALF_LANES', '')
     serial, splan = run()
-    assert splan.side_lanes == {'fpn': False, 'branch1': False, 'p4': False, 'half_batch_stages': []}
+    assert splan.side_lanes == {'fpn': False, 'branch1': False, 'p4': False, 'half_batch_stages': [], 'cls_tower': False}
     assert (serial[0][2] > 0.05).sum() > 0
     for got in lanes:
         for a, b in zip(got, serial[0]):
@@ -221,10 +221,16 @@ def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
 PLAN_OPTIONS = [{}, {'GPP_HALF_LANES': '1,2'}, {'GPP_HALF_LANES': '1'}, {'GPP_HALF_LANES': '2'}, {'GPP_HALF_LANES': '0,1,2,3'}, {'GPP_HALF_LANES': '0,2'},
                 {'GPP_HALF_LANES': ''}, {'GPP_BR1_LANE': '0'}, {'GPP_FPN_LANES': '0'}, {'GPP_P4_LANE': '0'}, {'GPP_HEAD_LANES': '1'},
                 {'GPP_DECODE_OVERLAP': '0'}, {'GPP_STAGE_CHUNKS': '4,8,8,8'}, {'GPP_STAGE_CHUNKS': '2,4,8,8', 'GPP_HALF_LANES': '2,3'},
-                {'GPP_HALF_LANES': '3', 'GPP_FPN_LANES': '0', 'GPP_BR1_LANE': '0'}]
+                {'GPP_HALF_LANES': '3', 'GPP_FPN_LANES': '0', 'GPP_BR1_LANE': '0'}, {'GPP_CLS_LANE': '1'}, {'GPP_CLS_LANE': '1', 'GPP_HALF_LANES': ''}]
 
 
-@pytest.mark.parametrize('options', PLAN_OPTIONS, ids=[' '.join('{}={}'.format(*kv) for kv in o.items()) or 'default' for o in PLAN_OPTIONS])
+# the default GPU run keeps the settings that changed a plan's shape in a way of its own (the default, the split / unsplit pattern of the round-4 race,
+# towers on side streams, chunked stages, no half batches); the rest of the matrix runs under --run-slow (tools/collect_r5.sh)
+PLAN_OPTIONS_DEFAULT_RUN = (0, 1, 6, 10, 13, 15)
+
+
+@pytest.mark.parametrize('options', [o if i in PLAN_OPTIONS_DEFAULT_RUN else pytest.param(o, marks=pytest.mark.slow) for i, o in enumerate(PLAN_OPTIONS)],
+                         ids=[' '.join('{}={}'.format(*kv) for kv in o.items()) or 'default' for o in PLAN_OPTIONS])
 def test_every_plan_variant_orders_its_streams_and_gives_the_same_bytes(options, monkeypatch):
     """ The plan builder puts launches on side streams by hand (half batches of res3-res5, projection shortcuts, small FPN launches,
     the detection selection).  Plan.check_stream_ordering replays gpp_plan_run's fork / join rules over the bytes every launch reads and
@@ -240,7 +246,7 @@ def test_every_plan_variant_orders_its_streams_and_gives_the_same_bytes(options,
     inputs = [x, P, np.tile(planes[None], (4, 1, 1))]
 
     def run(env):
-        for k in ('GPP_HALF_LANES', 'GPP_BR1_LANE', 'GPP_FPN_LANES', 'GPP_P4_LANE', 'GPP_HEAD_LANES', 'GPP_DECODE_OVERLAP', 'GPP_STAGE_CHUNKS'):
+        for k in ('GPP_HALF_LANES', 'GPP_BR1_LANE', 'GPP_FPN_LANES', 'GPP_P4_LANE', 'GPP_HEAD_LANES', 'GPP_DECODE_OVERLAP', 'GPP_STAGE_CHUNKS', 'GPP_CLS_LANE'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -252,7 +258,7 @@ def test_every_plan_variant_orders_its_streams_and_gives_the_same_bytes(options,
 
     got, plan = run(options)
     assert plan.check_stream_ordering() == []
-    serial, splan = run({'GPP_HALF_LANES': '', 'GPP_BR1_LANE': '0', 'GPP_FPN_LANES': '0', 'GPP_DECODE_OVERLAP': '0'})
+    serial, splan = run({'GPP_HALF_LANES': '', 'GPP_BR1_LANE': '0', 'GPP_FPN_LANES': '0', 'GPP_DECODE_OVERLAP': '0', 'GPP_CLS_LANE': '0'})
     assert splan.check_stream_ordering() == [] and all((f >> 8) & 0xff == 0 for f in splan.lanes)        # everything on the caller's stream
     for a, b in zip(got, serial):
         assert helpers.bits_equal(a, b)
@@ -489,9 +495,11 @@ def test_frame_pipeline_matches_synchronous_calls(model50):
             assert helpers.bits_equal(a, b) if a.dtype.kind == 'f' else np.array_equal(a, b)
 
 
-@pytest.mark.parametrize('backbone,dtype,fuse_next', [('resnet50', 'bf16', '0'), ('resnet101', 'f16', '0'), ('resnet152', 'bf16', '0'),
-                                                      ('resnet50', 'f32', '0'), ('resnet101', 'f32', '0'),
-                                                      ('resnet50', 'bf16x3', '0'), ('resnet50', 'f16x3', '0'), ('resnet101', 'f16x3', '0')])
+@pytest.mark.parametrize('backbone,dtype,fuse_next', [('resnet50', 'bf16', '0'), pytest.param('resnet101', 'f16', '0', marks=pytest.mark.slow),
+                                                      ('resnet152', 'bf16', '0'), ('resnet50', 'f32', '0'),
+                                                      pytest.param('resnet101', 'f32', '0', marks=pytest.mark.slow),
+                                                      pytest.param('resnet50', 'bf16x3', '0', marks=pytest.mark.slow),
+                                                      ('resnet50', 'f16x3', '0'), ('resnet101', 'f16x3', '0')])
 def test_every_layer_on_oracle_inputs(backbone, dtype, fuse_next, monkeypatch):
     check_every_layer(backbone, dtype, fuse_next, 2, 120, 200, monkeypatch)
 

@@ -135,6 +135,8 @@ def main():
     ap.add_argument('--backbone', default='resnet50')
     ap.add_argument('--planes', default='1k')
     ap.add_argument('--n', type=int, default=60)
+    ap.add_argument('--host-variants', action='store_true', help='also time packed / separate fetch x pinned / pageable upload')
+    ap.add_argument('--variants', default=None, help='plan-builder environment settings to compare with the default: "A=1,B=2;C=3"')
     args = ap.parse_args()
     import torch
     torch.cuda.set_device(0)
@@ -143,14 +145,35 @@ def main():
     model = models.load_model('synthetic:1234', backbone_name=args.backbone, dtype=args.dtype)
     planes = synthetic.load_plane_database(args.planes).astype(np.float32)
     rec = measure(model, planes, n=args.n)
-    # the two host-side choices of the bracket, each against the other form (same process, same plan)
-    rec['variants_sync_ms_median'] = {}
-    for fetch in ('packed', 'separate'):
-        for upload in ('pinned', 'pageable'):
-            os.environ['GPP_FETCH'], os.environ['GPP_UPLOAD'] = fetch, upload
-            r = measure(model, planes, n=max(20, args.n // 2))
-            rec['variants_sync_ms_median']['fetch={} upload={}'.format(fetch, upload)] = [r['sync_ms_median'], r['upload_ms'], r['fetch_ms']]
-    del os.environ['GPP_FETCH'], os.environ['GPP_UPLOAD']
+    if args.host_variants:
+        # the two host-side choices of the bracket, each against the other form (same process, same plan)
+        rec['variants_sync_ms_median'] = {}
+        for fetch in ('packed', 'separate'):
+            for upload in ('pageable', 'pinned'):
+                os.environ['GPP_FETCH'], os.environ['GPP_UPLOAD'] = fetch, upload
+                r = measure(model, planes, n=max(20, args.n // 2))
+                rec['variants_sync_ms_median']['fetch={} upload={}'.format(fetch, upload)] = [r['sync_ms_median'], r['upload_ms'], r['fetch_ms']]
+        del os.environ['GPP_FETCH'], os.environ['GPP_UPLOAD']
+    # plan-builder settings against the default, each on a fresh model in this process (same box, same minute): "A=1,B=2;C=3" = two variants
+    rec['plan_variants'] = {}
+    for variant in [v for v in (args.variants or '').split(';') if v.strip()]:
+        saved = {}
+        for kv in variant.split(','):
+            k, v = kv.split('=', 1)
+            saved[k] = os.environ.get(k)
+            os.environ[k] = v
+        m = models.load_model('synthetic:1234', backbone_name=args.backbone, dtype=args.dtype)
+        if os.environ.get('B1_GRAPH') == '1':              # (pseudo-setting of this tool: the plan replayed as ONE HIP-graph launch)
+            m.capture(m.plan_for(1, 402, 1333, planes.shape[0], True))
+        r = measure(m, planes, n=max(20, args.n // 2))
+        rec['plan_variants'][variant] = {k: r[k] for k in ('sync_ms_median', 'plan_only_ms_median', 'stages_ms', 'launches')}
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+        del m
+        torch.cuda.empty_cache()
     rec['dtype'], rec['backbone'] = args.dtype, args.backbone
     from keras_retinanet_3D.backend import hip
     rec['library'] = hip.lib().gpp_version().decode()
