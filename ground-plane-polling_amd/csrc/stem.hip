@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
 // halves (hi = f16(v), lo = f16(v - hi): 22 significant bits; |x| <= 152 and the weights carry a per-channel power of two, so both
 // halves are normal halfs) and every product is three matrix products, hi*whi + hi*wlo + lo*whi, accumulated in float32; the
 // output is float32.  Replaces the float32 fmaf stem of rounds 1-2 for these types: that kernel ran at a fifth of the vector peak
-// and lost another third of its speed when the packed-FP32 instructions went (372 us at B = 8; this one: see DESIGN 4.9).
+// and lost another third of its speed when the packed-FP32 instructions went (372 us at B = 8; this one: see HISTORY.md 4.9).
 // ROWS wavefronts per workgroup, each owning one output row of 64 pixels x 64 channels of a ROWS x 64 tile; persistent workgroups.
 // Packed weights: [whi 64 x 232 halfs][wlo 64 x 232 halfs][64 float32 out_scale] (gpp_stem_pack_weights_f16x3).
 template <int ROWS>

@@ -3,7 +3,7 @@ What the amdgpu driver reports about THIS process's card while it works: shader 
 power1_input / power1_average, power1_cap) by a sampling thread.  No GPU call, no child process: file reads every few tens of milliseconds.
 
 The dominant kernel of this path runs at the clock the power management grants under matrix load, and that clock depends on the operand
-data (2006 MHz at 1395 W of a 1400 W cap on real data, 2398 MHz on zeros, launch time in the same ratio).  `bench.py`
+data (HISTORY.md 4.10: 2006 MHz at 1395 W of a 1400 W cap on real data, 2398 MHz on zeros, launch time in the same ratio).  `bench.py`
 carries these medians next to `roofline` so that a reader can tell a schedule from a clock.  Everything here is optional: on a host that
 hides sysfs the sampler returns nothing.
 """

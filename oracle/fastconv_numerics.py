@@ -69,13 +69,52 @@ def pow2_scale(amax):
     return torch.pow(torch.tensor(2.0, dtype=torch.float64, device=amax.device), e)
 
 
+ACCUMULATION = 'mfma'      # 'mfma' | 'blas' (main() sets it)
+
+
+def mfma_accumulate(ah, al, wh, wl, rows=4096):
+    """ what a chain of v_mfma_f32_16x16x32_f16 does to one accumulator: per K-step of 32 channels three instructions (hi.wlo, hi.whi,
+    lo.whi, the kernels' order), each adding the sum of its 32 products -- products of halves are exact in float32, and their sum is formed
+    before the instruction rounds (profiles/r3/x3_error_probe.txt: the reason f16x3 is closer to float64 than a float32 MFMA chain, which
+    rounds after every 4 products) -- to the float32 accumulator with ONE rounding.  Emulated literally: the 32-product sums in float64,
+    the running accumulator rounded to float32 after every instruction.  (.., M, K) x (.., K, N); K a multiple of 32 (zero-padded). """
+    lead = ah.shape[:-2]
+    M, K = ah.shape[-2:]
+    N = wh.shape[-1]
+    pad = (-K) % 32
+    if pad:
+        ah, al = F.pad(ah, (0, pad)), F.pad(al, (0, pad))
+        wh, wl = F.pad(wh, (0, 0, 0, pad)), F.pad(wl, (0, 0, 0, pad))
+        K += pad
+    nb = K // 32
+    wh64 = wh.double().reshape(lead + (nb, 32, N))
+    wl64 = wl.double().reshape(lead + (nb, 32, N))
+    out = torch.empty(lead + (M, N), dtype=torch.float32, device=ah.device)
+    step = max(256, min(rows, (1 << 27) // max(1, nb * N * max(1, int(np.prod(lead))))))       # (.., nb, rows, N) float64 per term: <= 1 GB
+    for m0 in range(0, M, step):
+        a_h = ah[..., m0:m0 + step, :].double().reshape(lead + (-1, nb, 32)).transpose(-3, -2)      # (.., nb, m, 32)
+        a_l = al[..., m0:m0 + step, :].double().reshape(lead + (-1, nb, 32)).transpose(-3, -2)
+        terms = (torch.matmul(a_h, wl64), torch.matmul(a_h, wh64), torch.matmul(a_l, wh64))         # each (.., nb, m, N): exact 32-product sums
+        acc = torch.zeros(lead + (a_h.shape[-2], N), dtype=torch.float32, device=ah.device)
+        for b in range(nb):
+            for t in terms:
+                acc = (acc.double() + t[..., b, :, :]).float()
+        out[..., m0:m0 + step, :] = acc
+    return out
+
+
 def x3_gemm(A, Wm):
-    """ A (.., M, K) float32 x Wm (.., K, N) float64 (unscaled) -> float32 (.., M, N): three half products in one float32 accumulation """
+    """ A (.., M, K) float32 x Wm (.., K, N) float64 (unscaled) -> float32 (.., M, N): three half products per float32 product,
+    accumulated as the matrix pipe does (ACCUMULATION 'mfma') or by one float32 BLAS GEMM over the concatenated K ('blas': another
+    summation order, rounding after every product pair -- noisier than the hardware) """
     s = pow2_scale(Wm.abs().amax(dim=-2))                       # per output column (and per leading index: the Winograd position)
     ws = (Wm * s.unsqueeze(-2)).float()
     ah, al = split_half(A)
     wh, wl = split_half(ws)
-    acc = torch.matmul(torch.cat([ah, ah, al], dim=-1), torch.cat([wl, wh, wh], dim=-2))
+    if ACCUMULATION == 'mfma':
+        acc = mfma_accumulate(ah, al, wh, wl)
+    else:
+        acc = torch.matmul(torch.cat([ah, ah, al], dim=-1), torch.cat([wl, wh, wh], dim=-2))
     return acc * (1.0 / s).float().unsqueeze(-2)                # exact (power of two)
 
 
@@ -198,6 +237,7 @@ def main():
     ap.add_argument('--device', default='cuda' if torch.cuda.is_available() else 'cpu')
     ap.add_argument('--only', default=None, help='substrings of run names, separated by ;')
     ap.add_argument('--json', default=None)
+    ap.add_argument('--accumulation', default='mfma', choices=['mfma', 'blas'])
     ap.add_argument('--height', type=int, default=402, help='(smaller frames: a smoke run of the script, no fixture to compare with)')
     ap.add_argument('--width', type=int, default=1333)
     args = ap.parse_args()
@@ -208,6 +248,8 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import corner_deviation as CD
     torch.backends.cuda.matmul.allow_tf32 = False
+    global ACCUMULATION
+    ACCUMULATION = args.accumulation
     backbone, db = args.config.split('_')
     full = (args.height, args.width) == (402, 1333)
     lib_path = os.path.join(ROOT, 'oracle', 'liboracle_polling.so')
@@ -228,7 +270,7 @@ def main():
             runs.append(('{} on {}'.format(label, what), {nm: mode for nm in names}))
     if args.only:
         runs = [r for r in runs if any(s in r[0] for s in args.only.split(';'))]
-    report = {'config': args.config, 'frames': int(n), 'device': args.device, 'rows': {}}
+    report = {'config': args.config, 'frames': int(n), 'device': args.device, 'accumulation': args.accumulation, 'rows': {}}
 
     def print_row(name, r):
         d = r['distribution']
@@ -238,7 +280,7 @@ def main():
                                             d.get('corner_above_1e-3', 0), d.get('scaled_beyond_max', 0.0), r['meets_reference_bars'])), flush=True)
 
     if full:
-        print('{}: {} frames against tests/golden/fullsize_{}_f64.npz; bars: utils/ledger.REFERENCE_BARS, unchanged'.format(args.config, n, args.config))
+        print('{}: {} frames against tests/golden/fullsize_{}_f64.npz; bars: utils/ledger.REFERENCE_BARS, unchanged; accumulation model: {}'.format(args.config, n, args.config, args.accumulation))
         print(' | '.join(('run', 'dets', 'unexplained set diff', 'ties', 'plane', 'flips', 'n<=100m', 'p50', 'p99', 'max', '>1e-3', 'scaled max >100m', 'bars met')))
         report['rows']['float32 CPU oracle vs f64 oracle (float32 itself)'] = CD.compare(g64, g32, ledger)
         print_row('float32 CPU oracle vs f64 oracle (float32 itself)', report['rows']['float32 CPU oracle vs f64 oracle (float32 itself)'])

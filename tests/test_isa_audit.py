@@ -35,7 +35,7 @@ def test_no_kernel_spills_to_scratch(kernels):
 
 def test_the_power_bound_x3_loops_accumulate_in_place(kernels):
     """ an accumulating MFMA that writes another register than the one it reads costs a power-bound loop 20 % at the same instruction count
-    (profiles/r4/kws_shared_taps.txt): the three-phase x3 loops -- pipelined tiles on pre-split maps, the dual-shape and
+    (HISTORY.md 4.10, profiles/r4/kws_shared_taps.txt): the three-phase x3 loops -- pipelined tiles on pre-split maps, the dual-shape and
     the mixed-height grids -- must not have one.  (The loops the compiler schedules itself have some; they belong to HBM-bound layers.) """
     import re
     pipelined_x3 = re.compile(r'conv_igemm_kernelILi[45]ELi\d+ELi\d+ELi\d+ELi\d+ELi2ELb1ELb1E|conv_igemm_mix_kernelILi[45]E|conv_igemm_dual_kernelILi[45]ELb1E')

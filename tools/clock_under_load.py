@@ -2,7 +2,7 @@
 """
 The clock and the power the device reports while the dominant kernel runs -- on real operand data and on zeros.
 
-DESIGN.md 4.9 / 4.10 say the regression-tower kernel is bound by the clock the power management grants under matrix load, and that the
+HISTORY.md 4.9 / 4.10 (DESIGN.md 4.1 in short) say the regression-tower kernel is bound by the clock the power management grants under matrix load, and that the
 clock depends on the operand data.  The evidence so far was indirect (the same launch is 25 % faster on all-zero activations; the
 register-only loops of tools/micro).  This reads what the driver itself reports -- sysfs (hwmon freq1_input / power1_average, pp_dpm_sclk)
 or, failing that, `rocm-smi --showclocks --showpower --json` -- every 50 ms while one thread launches the layer back to back for a few seconds.

@@ -4,7 +4,7 @@
     context save can lose lanes 48-63 of such a result on this platform (csrc/poll.hip header, DESIGN.md section 4.4);
   * scratch (register spills) per kernel: private_segment_fixed_size / spill counts from the code-object metadata;
   * (informational, `--mfma`) accumulating MFMAs whose destination is NOT their accumulator operand (vdst != srcC): in a power-bound loop an
-    out-of-place accumulation costs 20 % at the same instruction count.  The three-phase x3 loops must have none.
+    out-of-place accumulation costs 20 % at the same instruction count (HISTORY.md 4.10).  The three-phase x3 loops must have none.
 
     python tools/isa_audit.py [path/to/lib.so] [--json out.json] [--allow-scratch REGEX] [--warn-scratch] [--mfma]
 Exit code 1 when a packed-FP32 instruction is found, when a kernel not matched by --allow-scratch uses scratch (--warn-scratch:
