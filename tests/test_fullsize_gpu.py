@@ -46,7 +46,7 @@ def _heads(plan, batch):
             'classification_logits': plan.cls_logits.cpu().numpy().reshape(batch, -1, 8)}
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'f32', 'f16x3', pytest.param('f16', marks=pytest.mark.slow), pytest.param('bf16x3', marks=pytest.mark.slow)])
+@pytest.mark.parametrize('dtype', ['f32', 'f16x3'] + [pytest.param(t, marks=pytest.mark.slow) for t in ('bf16', 'f16', 'bf16x3')])
 def test_every_layer_at_402x1333(dtype, monkeypatch):
     check_every_layer('resnet50', dtype, '0', 2, H, WD, monkeypatch)
 
@@ -146,6 +146,7 @@ def test_parity_ledger_of_the_16_bit_paths(dtype, f32_run):
         assert ledger.meets_reference_bars(led, pair=True), led
 
 
+@pytest.mark.slow          # (a full-size forward of the CPU oracle in 16-bit-storage mode: self-consistency of the bf16 path, 10 s of host time)
 def test_conv_stack_at_402x1333_matches_the_storage_oracle():
     """ whole bf16 stack against the oracle in 16-bit storage mode and against the float32 oracle, bars of
     tests/test_network_gpu.py::test_conv_stack_matches_oracle, at the BASELINE size """

@@ -71,7 +71,7 @@ def test_conv_stack_matches_oracle(model50, batch, h, w):
         assert np.sqrt((ef ** 2).mean()) < 0.015 * scale and ef.max() < 0.25, (key, ef.max())
 
 
-@pytest.mark.parametrize('backbone', ['resnet50', 'resnet101', 'resnet152'])
+@pytest.mark.parametrize('backbone', ['resnet50', pytest.param('resnet101', marks=pytest.mark.slow), 'resnet152'])
 def test_predict_on_batch_end_to_end(backbone, oracle_lib):
     batch, h, w = 2, 128, 224
     model = models.load_model('synthetic:7', backbone_name=backbone, dtype='bf16')
@@ -226,7 +226,7 @@ PLAN_OPTIONS = [{}, {'GPP_HALF_LANES': '1,2'}, {'GPP_HALF_LANES': '1'}, {'GPP_HA
 
 # the default GPU run keeps the settings that changed a plan's shape in a way of its own (the default, the split / unsplit pattern of the round-4 race,
 # towers on side streams, chunked stages, no half batches); the rest of the matrix runs under --run-slow (tools/collect_r5.sh)
-PLAN_OPTIONS_DEFAULT_RUN = (0, 1, 6, 10, 13, 15)
+PLAN_OPTIONS_DEFAULT_RUN = (0, 1, 10, 15)
 
 
 @pytest.mark.parametrize('options', [o if i in PLAN_OPTIONS_DEFAULT_RUN else pytest.param(o, marks=pytest.mark.slow) for i, o in enumerate(PLAN_OPTIONS)],
@@ -285,7 +285,7 @@ def test_the_stream_ordering_check_sees_a_missing_join(monkeypatch):
     assert any(later == 'P4' for _, later in plan.check_stream_ordering())
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'f16x3'])
+@pytest.mark.parametrize('dtype', [pytest.param('bf16', marks=pytest.mark.slow), 'f16x3'])
 def test_random_tiles_never_change_a_byte(dtype, monkeypatch):
     """ GPP_TUNE_RANDOM: every conv layer (and fused tail) of the plan takes a RANDOM tile among the autotuner's candidates
     (gpp_conv2d_tile_candidates) instead of the fastest one -- three different draws and the measured choice give identical output
@@ -496,7 +496,7 @@ def test_frame_pipeline_matches_synchronous_calls(model50):
 
 
 @pytest.mark.parametrize('backbone,dtype,fuse_next', [('resnet50', 'bf16', '0'), pytest.param('resnet101', 'f16', '0', marks=pytest.mark.slow),
-                                                      ('resnet152', 'bf16', '0'), ('resnet50', 'f32', '0'),
+                                                      pytest.param('resnet152', 'bf16', '0', marks=pytest.mark.slow), ('resnet50', 'f32', '0'),
                                                       pytest.param('resnet101', 'f32', '0', marks=pytest.mark.slow),
                                                       pytest.param('resnet50', 'bf16x3', '0', marks=pytest.mark.slow),
                                                       ('resnet50', 'f16x3', '0'), ('resnet101', 'f16x3', '0')])

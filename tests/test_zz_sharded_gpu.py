@@ -46,7 +46,7 @@ def _run_shards(dtype, batch, h, w, tmp_path, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', ['f16x3', 'f32', pytest.param('bf16', marks=pytest.mark.slow), pytest.param('bf16x3', marks=pytest.mark.slow)])
+@pytest.mark.parametrize('dtype', ['f16x3'] + [pytest.param(t, marks=pytest.mark.slow) for t in ('f32', 'bf16', 'bf16x3')])
 def test_two_process_shards_equal_the_single_process_batch(dtype, tmp_path, oracle_lib):
     """ STRICT: the first mismatch fails (round 2 re-ran a mismatch once and only warned; the transient it tolerated was real -- a
     wavefront of the polling kernel resumed after a context save with 16 lanes of a packed-FP32 result missing, see

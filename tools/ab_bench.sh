@@ -9,7 +9,7 @@ for r in $(seq 1 $R); do
     for which in A B; do
         lib=$A; [ $which = B ] && lib=$B
         extra=$AB_ENV_A; [ $which = B ] && extra=$AB_ENV_B
-        env $extra GPP_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-f32-leg --no-host-fed --steps 40 "$@" > gpurun_out/ab_$which$r.json 2> gpurun_out/ab_$which$r.err || { echo "bench failed ($which$r)"; tail -5 gpurun_out/ab_$which$r.err; exit 1; }
+        env $extra GPP_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-f32-leg --no-host-fed --no-b1 --repeats 0 --steps 40 "$@" > gpurun_out/ab_$which$r.json 2> gpurun_out/ab_$which$r.err || { echo "bench failed ($which$r)"; tail -5 gpurun_out/ab_$which$r.err; exit 1; }
         python - <<P
 import json
 d = json.load(open('gpurun_out/ab_$which$r.json'))

@@ -9,7 +9,7 @@ for r in $(seq 1 $R); do
   for setting in "$@"; do
     i=$((i+1))
     s="$setting"; [ "$s" = "-" ] && s=""
-    env $s python bench.py --no-cpu-baseline --no-f32-leg --no-host-fed --steps 40 ${AB_ARGS} > gpurun_out/ab_env_$i.json 2> gpurun_out/ab_env_$i.err || { echo "bench failed ($setting)" >> $out; tail -3 gpurun_out/ab_env_$i.err >> $out; continue; }
+    env $s python bench.py --no-cpu-baseline --no-f32-leg --no-host-fed --no-b1 --repeats 0 --steps 40 ${AB_ARGS} > gpurun_out/ab_env_$i.json 2> gpurun_out/ab_env_$i.err || { echo "bench failed ($setting)" >> $out; tail -3 gpurun_out/ab_env_$i.err >> $out; continue; }
     python - "$setting" $r >> $out <<'P'
 import json, sys, glob
 d = json.load(open(sorted(glob.glob('gpurun_out/ab_env_*.json'), key=lambda p: __import__('os').path.getmtime(p))[-1]))

@@ -4,11 +4,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=${1:-gpurun_out/pmc_x3}
 mkdir -p $out
 export GPP_TUNE_CACHE=$GRAFT_REPO_ROOT/$out/tune_cache.json
-python3 bench.py --dtype bf16x3 --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --no-host-fed > $out/tuning_run.log 2>&1
+python3 bench.py --dtype bf16x3 --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --no-host-fed --no-b1 --repeats 0 > $out/tuning_run.log 2>&1
 tail -c 600 $out/tuning_run.log
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_LDS"; do
   name=$(echo $c | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$name -- python3 bench.py --dtype bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-f32-leg --no-host-fed > $out/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$name -- python3 bench.py --dtype bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-f32-leg --no-host-fed --no-b1 --repeats 0 > $out/$name.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections

@@ -14,8 +14,8 @@ mkdir -p $out
 # as two half batches on two streams and P5 / P6 / P7 / P4 on side streams, ~4 % faster on the step; the dominant kernel is not touched by that)
 export GPP_FPN_LANES=0 GPP_BR1_LANE=0 GPP_HALF_LANES=
 export GPP_TUNE_CACHE=$GRAFT_REPO_ROOT/$out/tune_cache.json
-python3 bench.py --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --no-host-fed > $out/tuning_run.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --no-f32-leg --no-host-fed > $out/bench_under_rocprof.log 2>&1
+python3 bench.py --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --no-host-fed --no-b1 --repeats 0 > $out/tuning_run.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --no-f32-leg --no-host-fed --no-b1 --repeats 0 > $out/bench_under_rocprof.log 2>&1
 grep '^{"metric"' $out/bench_under_rocprof.log > $out/bench_under_rocprof.json
 trace=$(find $out/trace -name '*kernel_trace.csv' | head -1)
 stats=$(find $out/trace -name '*kernel_stats.csv' | head -1)
