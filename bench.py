@@ -51,7 +51,7 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3
 # measured once, not by this script): the clock under matrix load depends on the data, zeros run at the nominal figure above
 PIPE_ON_RANDOM_DATA_TFLOPS = {'bf16': 2033.9, 'f16': 1753.4, 'bf16x3': 2033.9 / 3.0, 'f16x3': 1753.4 / 3.0}
 PIPE_ON_POST_RELU_DATA_TFLOPS = {'bf16': 2134.7, 'f16': 1961.8, 'bf16x3': 2134.7 / 3.0, 'f16x3': 1961.8 / 3.0}      # half of the activation values zero
-PROFILE_ROUNDS = ('r4', 'r3')      # the PMC file of the newest round whose library hash matches the running build is quoted
+PROFILE_ROUNDS = ('r5', 'r4', 'r3')      # the PMC file of the newest round whose library hash matches the running build is quoted
 # algorithmic bytes of one regression-tower launch at B = 8: M x 512 channels in + out and the packed weights,
 # 2 bytes per element for the 16-bit storage types, 4 for the float32-sized maps of f32 / bf16x3 / f16x3
 ALGORITHMIC_MB = {'bf16': 192.1, 'f16': 192.1, 'f32': 384.2, 'bf16x3': 384.2, 'f16x3': 384.2}
