@@ -29,6 +29,14 @@ constexpr int kWinoPairs = 192, kWinoCols = 128;                  // per-positio
 constexpr int kWinoStage = (kWinoPairs + kWinoCols) * kRowBytes;  // 40 KB
 constexpr int kWinoPieces = (kWinoPairs + kWinoCols) / 8 / 8;     // 1 KB (8-row) LDS-DMA pieces per wavefront and stage: 5
 constexpr int kWinoAPieces = kWinoPairs / 8;                      // pieces 0..23 are activation rows, 24..39 weight rows
+// stages of the LDS ring.  The DMA of a stage goes out right behind the barrier of the step that has finished with its buffer and is first read
+// kWinoStages - 1 steps later: with two stages one K-step (~0.9 us) of latency tolerance, with three two.  On an LDS / L2-resident image the
+// third stage buys nothing (tools/micro/kstep_wino.hip); on the real layer the activation rows of V are first touches from HBM.
+#ifndef GPP_WINO_STAGES
+#define GPP_WINO_STAGES 3
+#endif
+constexpr int kWinoStages = GPP_WINO_STAGES;
+static_assert(kWinoStages == 2 || kWinoStages == 3, "two or three stages");
 
 struct WinoTiles { int tile_start[GPP_MAX_GROUPS + 1]; };         // first M tile of every group (prefix sums), filled in by the launcher
 
@@ -163,8 +171,7 @@ __global__ __launch_bounds__(512, 1) void wino_conv_kernel(const gpp_wino_desc d
         ++iks;
         if (++ikh == 3) { ikh = 0; if (++ic == chunks) { ic = 0; ++ip; } }
     };
-    issue(wsm);
-    issue(wsm + kWinoStage);
+    for (int st = 0; st < kWinoStages; ++st) issue(wsm + st * kWinoStage);
 
     const int frow = lane & 15, fq = lane >> 4;
     int a_rd[2], b_rd[2];
@@ -189,9 +196,11 @@ __global__ __launch_bounds__(512, 1) void wino_conv_kernel(const gpp_wino_desc d
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     // one K-step: the software pipeline runs across position boundaries (the stage of step ks + 2 may belong to the next position)
+    int cur = 0;                                 // ring slot of the stage being computed
     auto kstep = [&](const int ks) {
-        unsigned char* scur = wsm + (ks & 1) * kWinoStage;
-        const unsigned char* snxt = wsm + ((ks & 1) ^ 1) * kWinoStage;
+        unsigned char* scur = wsm + cur * kWinoStage;
+        const int nxt = cur + 1 == kWinoStages ? 0 : cur + 1;
+        const unsigned char* snxt = wsm + nxt * kWinoStage;
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase A: hi * wlo; reads whi
 #pragma unroll
@@ -210,13 +219,15 @@ __global__ __launch_bounds__(512, 1) void wino_conv_kernel(const gpp_wino_desc d
             for (int j = 0; j < NF; ++j) { const int js = (gi & 1) ? NF - 1 - j : j; wino_mfma(M[gi][js], bh[js], ah[gi]); }
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next stage has landed
+        // the next stage has landed: everything issued so far (two stages), or everything but the newest stage's pieces (three: loads return in order)
+        if (kWinoStages == 2 || ks + kWinoStages > ksteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWinoPieces) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront has read what it needs of the current one
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase C: lo * whi; the stage after next goes out into the buffer this step has finished with; reads hi, wlo of the next step
-        if (ks + 2 < ksteps) issue(scur);
+        if (ks + kWinoStages < ksteps) issue(scur);
 #pragma unroll
         for (int gi = 0; gi < MF; ++gi) {
             ah[gi] = *(const f16x8*)(snxt + a_rd[0] + gi * 16 * kRowBytes);
@@ -226,6 +237,7 @@ __global__ __launch_bounds__(512, 1) void wino_conv_kernel(const gpp_wino_desc d
             for (int j = 0; j < NF; ++j) { const int js = (gi & 1) ? NF - 1 - j : j; wino_mfma(M[gi][js], bh[js], al[gi]); }
             __builtin_amdgcn_sched_barrier(0);
         }
+        cur = nxt;
     };
     // ONE copy of the K-step in the code (several copies make the register allocator rotate the accumulators through them: out-of-place MFMAs,
     // spills -- HISTORY.md 4.10): a loop over the positions around the loop over a position's K-steps, the fold between them
@@ -344,11 +356,11 @@ int gpp_wino_conv_dispatch_f16x3(const gpp_wino_desc& host, hipStream_t st)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GPP_ERR_UNSUPPORTED;
     if (!(configured.load(std::memory_order_acquire) >> dev & 1ull)) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWinoStage);
+        hipError_t e = hipFuncSetAttribute((const void*)wino_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoStages * kWinoStage);
         if (e != hipSuccess) return (int)e;
         configured.fetch_or(1ull << dev, std::memory_order_release);
     }
-    wino_conv_kernel<<<total_wgs, 512, 2 * kWinoStage, st>>>(d, tiles, n_tiles_n, total_wgs);
+    wino_conv_kernel<<<total_wgs, 512, kWinoStages * kWinoStage, st>>>(d, tiles, n_tiles_n, total_wgs);
     return (int)hipGetLastError();
 }
 

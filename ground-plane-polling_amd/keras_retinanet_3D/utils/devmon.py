@@ -71,7 +71,7 @@ class Sampler(object):
             rec = read(self.src)
             if rec:
                 self.samples.append(rec)
-            time.sleep(self.period)
+            self._stop.wait(self.period)                 # (returns at once when the region ends, whatever the period)
 
     def __exit__(self, *exc):
         self._stop.set()

@@ -15,9 +15,10 @@ step b1_floors;    python tools/fill_floor_table.py f16x3 resnet50 1 2>/dev/null
 step profile;      bash tools/profile_bench.sh $o/prof f16x3 > $o/profile_bench.log 2>&1; tail -4 $o/profile_bench.log
 step pmc;          bash tools/pmc_bench.sh $o/pmc f16x3 > $o/pmc_bench.log 2>&1; tail -12 $o/pmc_bench.log
 step wino;         python tools/bench_wino.py 8 20 > $o/bench_wino_b8.txt 2>&1; tail -3 $o/bench_wino_b8.txt | cut -c1-300; python tools/bench_wino.py 1 30 > $o/bench_wino_b1.txt 2>&1
-step ab_wino;      bash tools/ab_env.sh $o/ab_wino.txt 3 - GPP_WINO=1 > /dev/null 2>&1; cat $o/ab_wino.txt
+step ab_wino;      bash tools/ab_env.sh $o/ab_wino.txt 3 - GPP_WINO=1 GPP_CLS_LANE=1 > /dev/null 2>&1; cat $o/ab_wino.txt
 python tools/isa_audit.py --json $o/kernel_resources.json | tail -1
 else
+step smoke;        python __graft_entry__.py smoke 2>&1 | tail -1 | cut -c1-300
 step gpu_suite;    /usr/bin/time -v python -m pytest tests -m gpu -q --durations=15 > $o/gpu_suite_default.log 2>&1; tail -22 $o/gpu_suite_default.log
 step slow_suite;   python -m pytest tests -m "gpu and slow" -q --durations=10 > $o/gpu_suite_slow.log 2>&1; tail -14 $o/gpu_suite_slow.log
 fi
