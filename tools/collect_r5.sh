@@ -19,6 +19,6 @@ step ab_wino;      bash tools/ab_env.sh $o/ab_wino.txt 3 - GPP_WINO=1 GPP_CLS_LA
 python tools/isa_audit.py --json $o/kernel_resources.json | tail -1
 else
 step smoke;        python __graft_entry__.py smoke 2>&1 | tail -1 | cut -c1-300
-step gpu_suite;    /usr/bin/time -v python -m pytest tests -m gpu -q --durations=15 > $o/gpu_suite_default.log 2>&1; tail -22 $o/gpu_suite_default.log
+step gpu_suite;    python -m pytest tests -m gpu -q --durations=15 > $o/gpu_suite_default.log 2>&1; tail -22 $o/gpu_suite_default.log
 step slow_suite;   python -m pytest tests -m "gpu and slow" -q --durations=10 > $o/gpu_suite_slow.log 2>&1; tail -14 $o/gpu_suite_slow.log
 fi
