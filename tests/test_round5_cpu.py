@@ -1,0 +1,70 @@
+"""
+Host-side pieces of round 5 that need no GPU: the Winograd weight packing (layers/conv.pack_weight_wino), the emulation the numerics study
+rests on (oracle/fastconv_numerics.py) against float64, and the 'trained' weight family (models/weights.trained_like).
+"""
+import numpy as np
+import torch
+
+from keras_retinanet_3D.layers import conv as C
+from keras_retinanet_3D.models import weights as W
+from oracle import fastconv_numerics as FN
+from oracle import net_torch
+
+
+def test_winograd_weight_packing_is_the_transformed_kernel_in_the_kernels_layout():
+    rng = np.random.default_rng(0)
+    cin, cout = 64, 128
+    k = (rng.standard_normal((3, 3, cin, cout)) * np.logspace(-3, 1, cout)[None, None, None, :]).astype(np.float32)     # channels four decades apart
+    w, inv_scale = C.pack_weight_wino(k, 'cpu')
+    assert tuple(w.shape) == (cout, 4 * (cin // 32) * 3 * 32) and tuple(inv_scale.shape) == (4, cout)
+    halves = w.view(torch.float16).reshape(cout, 4, cin // 32, 3, 2, 32).float()               # [row][position][chunk][kernel row][hi | lo][32]
+    val = (halves[..., 0, :] + halves[..., 1, :]).numpy()
+    U = np.einsum('pw,hwcn->phcn', C.WINO_G, k.astype(np.float64))                              # (position, kernel row, c, n)
+    rows = C.weight_row_order(cout).numpy()
+    for row in (0, 17, 37, 127):
+        n = int(rows[row])
+        got = val[row] * inv_scale[:, n].numpy()[:, None, None, None]                           # undo the power-of-two scale
+        want = U[:, :, :, n].reshape(4, 3, cin // 32, 32).transpose(0, 2, 1, 3)
+        assert np.allclose(got, want, rtol=3e-7, atol=0.0)                                      # hi + lo carries 22 bits
+    # both halves of every stored weight are normal halfs or zero: the largest |U| of a (position, channel) sits in [2^13, 2^14)
+    amax = np.abs(val).reshape(cout, 4, -1).max(axis=2)
+    assert np.all((amax >= 2.0 ** 13) & (amax < 2.0 ** 14))
+    log2 = np.log2(inv_scale.numpy())
+    assert np.all(log2 == np.round(log2))                                                       # powers of two: the rescale is exact
+
+
+def test_the_emulated_arithmetic_of_the_numerics_study_matches_float64():
+    torch.manual_seed(0)
+    for (H, Wd, cin, cout) in [(13, 21, 64, 48), (7, 11, 128, 32), (5, 6, 32, 16), (4, 1, 32, 16)]:
+        x = FN.stored(torch.relu(torch.randn(1, cin, H, Wd)) * 3)
+        k = torch.randn(3, 3, cin, cout, dtype=torch.float64) * 0.05
+        ref = torch.nn.functional.conv2d(x.double(), k.permute(3, 2, 0, 1), padding=1)
+        for acc in ('mfma', 'blas'):
+            FN.ACCUMULATION = acc
+            for fn in (lambda: FN.conv_direct(x, k, 1, (1, 1, 1, 1)), lambda: FN.conv_w2(x, k), lambda: FN.conv_w4(x, k)):
+                y = fn()
+                assert y.shape == ref.shape
+                rel = float((y.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+                assert rel < 1e-6, (H, Wd, cin, cout, acc, rel)
+    FN.ACCUMULATION = 'mfma'
+
+
+def test_the_trained_weight_family_computes_the_base_function_with_other_statistics():
+    assert W.parse_synthetic('synthetic') == (1234, 'he') and W.parse_synthetic('synthetic:7') == (7, 'he')
+    assert W.parse_synthetic('synthetic:1234:trained') == (1234, 'trained') and W.parse_synthetic('synthetic:7.h5') == (7, 'he')
+    base = W.synthetic_weights('resnet50', 1234)
+    tr = W.synthetic_weights('resnet50', 1234, 'trained')
+    assert set(base) == set(tr)
+    W.validate_weights(tr, 'resnet50')
+    g = tr['bn3b_branch2a/gamma']
+    live = g[g > 0]
+    assert (g == 0).sum() >= 1 and live.max() / live.min() > 100.0                              # dead channels; scales decades apart
+    img = (np.random.default_rng(1).integers(0, 256, size=(1, 96, 160, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32))
+    a = net_torch.forward(base, img, 'resnet50', keep_features=True)
+    b = net_torch.forward(tr, img, 'resnet50', keep_features=True)
+    for level, gain in (('C3', W.TRAINED_STAGE_GAIN[1]), ('C4', W.TRAINED_STAGE_GAIN[2]), ('C5', W.TRAINED_STAGE_GAIN[3])):
+        ratio = float(np.abs(b[level]).mean() / np.abs(a[level]).mean())
+        assert 0.5 * gain < ratio < 2.0 * gain, (level, ratio)                                  # the residual stream grows stage by stage
+    # ... and the heads see (nearly) the base draw's features: only the dead channels change the function
+    assert abs(float(b['P3'].std() / a['P3'].std()) - 1.0) < 0.25
+    assert float(np.corrcoef(a['classification_logits'].ravel(), b['classification_logits'].ravel())[0, 1]) > 0.8
