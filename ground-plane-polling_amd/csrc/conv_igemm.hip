@@ -203,6 +203,7 @@ extern "C" int gpp_conv2d_igemm(const gpp_conv_desc* host_desc, void* stream)
 static const int kTiles[] = {0, 64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128,
                              1128128, 1192128, 1128256, 1160256, 1192256, 1224256, 256256, 1256256,
                              128160, 192160, 1192160, 1128160, 2256256, 1192096, 3256224, 3192160, 4128064, 4064064, 4128128, 4064128,
+                             5064064, 5096064, 5064128, 5096128, 5128128,      // x3 types, pre-split inputs: the plain loop on a four-deep ring
                              128256, 192256};            // GPP_BF16X3 only: 8-wavefront tiles with the plain loop
 // (the loader-wavefront form of round 2, tile codes 3064128 ..., measured 1.5 - 2x slower on every layer it was built for
 // (profiles/r2/ring_kernel.txt), is no longer part of the library)
@@ -213,7 +214,16 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
     int64_t rows = 0;
     for (int g = 0; g < desc->n_groups; ++g) rows += (int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out;
     const int bn = tile % 1000 ? tile % 1000 : 128;
-    if (tile >= 5000000) return false;
+    if (tile >= 5000000) {           // four-deep ring (x3 types, pre-split inputs): deep K, and a grid of at most ~one workgroup per CU
+        static const bool no_deep = [] { const char* e = getenv("GPP_NO_DEEP_TILES"); return e && e[0] == '1'; }();      // (A/B)
+        const bool x3_in = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);
+        const int bm = (tile / 1000) % 1000;
+        int64_t tiles_m = 0;
+        for (int g = 0; g < desc->n_groups; ++g) tiles_m += ((int64_t)desc->batch * desc->groups[g].H_out * desc->groups[g].W_out + bm - 1) / bm;
+        const int64_t wgs = tiles_m * ((desc->C_out + bn - 1) / bn) * (desc->split_k > 1 ? desc->split_k : 1);
+        if (bn == 64 && desc->C_out > 256) return false;
+        return !no_deep && x3_in && nk >= 12 && wgs <= 320;
+    }
     if (tile >= 4000000) {           // weight-stationary persistent 1 x 1 (x3 types, pre-split maps): the W n-tile and the ring have to fit 160 KB of LDS
         static const bool no_ws = [] { const char* e = getenv("GPP_NO_WS_TILES"); return e && e[0] == '1'; }();
         const bool x3_in = is_x3(desc->dtype) && (desc->x3_split & GPP_X3_IN);

@@ -2410,6 +2410,15 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                             case 4064064: return launch_ws<DT, 64, 64>(d, st);
                             case 4128128: return launch_ws<DT, 128, 128>(d, st);
                             case 4064128: return launch_ws<DT, 64, 128>(d, st);
+                            // 5000000 + BM * 1000 + BN: the plain loop on a FOUR-deep LDS ring (three K-steps of LDS-DMA in flight ahead of the one
+                            // computed).  For the launches that field at most one workgroup per CU anyway -- deep-K, small-M layers, every layer
+                            // at batch 1 -- whose K-steps are bound by the latency of their own tile loads; where more workgroups would share a CU
+                            // the larger footprint loses (round 2: 1.6 x slower at B = 8) and the tuner keeps the two-deep tiles.
+                            case 5064064: return launch<DT, 64, 64, 2, 2, 4, false, true>(d, st);
+                            case 5096064: return launch<DT, 96, 64, 2, 2, 4, false, true>(d, st);
+                            case 5064128: return launch<DT, 64, 128, 2, 2, 4, false, true>(d, st);
+                            case 5096128: return launch<DT, 96, 128, 2, 2, 4, false, true>(d, st);
+                            case 5128128: return launch<DT, 128, 128, 2, 2, 4, false, true>(d, st);
                             default: break;
                         }
                     }
@@ -2420,6 +2429,7 @@ int dispatch(gpp_conv_desc& d, hipStream_t st)
                 switch (d.tile_hint) {
                     case 256: case 1128128: case 1192128: case 1128256: case 1192256: case 1192160: case 1128160: case 2256256: case 512: case 256256: case 1256256:
                     case 192256: case 128256: case 1192096: case 3256224: case 3192160: case 1224256: case 1160256: case 4128064: case 4064064: case 4128128: case 4064128:
+                    case 5064064: case 5096064: case 5064128: case 5096128: case 5128128:
                         return GPP_ERR_UNSUPPORTED;
                     default: return GPP_ERR_BAD_ARG;
                 }

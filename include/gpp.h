@@ -163,7 +163,10 @@ typedef struct gpp_conv_desc {
                                        round quantisation of one-workgroup-per-CU tiles (GPP_ERR_UNSUPPORTED where it gains nothing);
                                        4128064 / 4064064 / 4128128 / 4064128 (4000000 + BM * 1000 + BN; 1 x 1, stride 1, one map, pre-split input / shortcut,
                                        C_out a multiple of BN with 32 % (C_out / BN) == 0, K small enough for BN x K weights + the activation ring in 160 KB of LDS): the
-                                       weight-stationary persistent form of the shallow 1 x 1 layers.
+                                       weight-stationary persistent form of the shallow 1 x 1 layers;
+                                       5064064 / 5096064 / 5064128 / 5096128 / 5128128 (5000000 + BM * 1000 + BN; x3 types, pre-split inputs): the plain loop on a
+                                       four-deep LDS ring -- for launches of at most about one workgroup per CU (deep-K small-M layers, batch 1), whose
+                                       K-steps are bound by the latency of their own tile loads.
                                        gpp_conv2d_tile_candidates lists what a given layer accepts; see gpp_conv2d_autotune */
     int32_t reserved;               /* must be 0 (anything else: GPP_ERR_BAD_ARG).  Only the diagnostic -DGPP_STAMPS build of the
                                        library (make stamps; tools/bench_conv.py) reads it: bit 0 skip the tile loads, bit 1 skip

@@ -27,6 +27,7 @@ pytestmark = pytest.mark.gpu
 
 PLAIN_TILES = [64064, 96064, 128064, 160064, 192064, 64128, 96128, 128128, 160128, 192128, 224128, 128160, 128256, 192256, 256256]
 PIPE_TILES = [1128128, 1192128, 1128256, 1160256, 1192256, 1224256, 1256256, 1128160, 1192096]
+DEEP_TILES = [5064064, 5096064, 5064128, 5096128, 5128128]          # the plain loop on a four-deep LDS ring (pre-split inputs; round 5)
 
 
 def held(t):
@@ -130,7 +131,7 @@ def test_f16x3_pre_split_maps(case, tile, flags):
 
 @pytest.mark.parametrize('case', ['3x3_wide', 'bottleneck_2c', '3x3_s2_tfsame', 'deepK', '1x1'])
 def test_every_f16x3_tile_gives_identical_results(case):
-    """ plain, 8-wavefront and software-pipelined tiles, float32 and pre-split input maps, with and without split-K: an output
+    """ plain, 8-wavefront, software-pipelined and four-deep-ring tiles, float32 and pre-split input maps, with and without split-K: an output
     element is summed in the same order (hi * wlo, hi * whi, lo * whi per K-step) -> identical bits """
     c = [c for c in CASES if c[0] == case][0]
     for flags in (0, 7):
@@ -140,7 +141,7 @@ def test_every_f16x3_tile_gives_identical_results(case):
             if nk < 4 * split_k:
                 continue
             base = None
-            for tile in PLAIN_TILES + ([192160] + PIPE_TILES if eff & 1 else []):
+            for tile in PLAIN_TILES + ([192160] + PIPE_TILES + DEEP_TILES if eff & 1 else []):
                 d = make(tile, split_k=split_k)
                 if not fits(d, tile):
                     continue
@@ -553,3 +554,23 @@ def test_weight_stationary_1x1_is_offered_where_it_applies():
     assert not (ws & cands(128, 128, 3, True))                                  # 3 x 3
     assert not (ws & cands(1024, 256, 1, True))                                 # 256 KB of weights
     assert not (ws & cands(256, 128, 1, True, stride=2))                        # strided
+
+
+def test_the_four_deep_ring_tiles_are_offered_to_small_grids_only():
+    """ tile codes 5BBBNNN: candidates for a deep-K layer whose grid is about one workgroup per CU (every layer at batch 1), not for a big grid """
+    dev = torch.device('cuda')
+
+    def candidates(B, H, W, cin, cout, split=True):
+        x = C.FMap.empty(B, H, W, cin, torch.float32, dev, split=split, half='f16x3')
+        o = C.FMap.empty(B, H, W, cout, torch.float32, dev, split=True, half='f16x3')
+        k = torch.zeros((3, 3, cin, cout)).numpy()
+        w, s = C.pack_weight(k, 'f16x3', dev), C.out_scale_of(k, dev)
+        d = C.conv_desc([x], [o], w, torch.zeros((cout,), device=dev), 3, 3, cin, cout, pad=(1, 1), dtype='f16x3', out_scale=s)
+        tiles, count = (ctypes.c_int * 64)(), ctypes.c_int(0)
+        hip.check(hip.lib().gpp_conv2d_tile_candidates(ctypes.byref(d), tiles, 64, ctypes.byref(count)), 'candidates')
+        return set(tiles[:count.value])
+
+    small = candidates(1, 26, 84, 256, 256)                    # res4 branch2b at batch 1: 35 x 2 tiles of 64 x 128
+    assert {5064064, 5064128, 5096128, 5128128} <= small
+    assert not (candidates(8, 51, 167, 128, 128) & set(DEEP_TILES))          # res3 branch2b at batch 8: hundreds of workgroups
+    assert not (candidates(1, 26, 84, 256, 256, split=False) & set(DEEP_TILES))      # float32 input maps: no
