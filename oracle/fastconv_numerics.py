@@ -297,8 +297,8 @@ def main():
                 outs[k].append(v)
             aidx.append(ai.astype(np.int32))
             pidx.append(idx)
-            if seed == 0:
-                print('  [{}] frame 0: {:.1f} s, {} layers in a Winograd form'.format(title, time.time() - t0, sum(1 for m in net.used.values() if m != 'x3')),
+            if seed == 0 or seed % 8 == 7:
+                print('  [{}] frame {}: {:.1f} s, {} layers in a Winograd form'.format(title, seed, time.time() - t0, sum(1 for m in net.used.values() if m != 'x3')),
                       file=sys.stderr, flush=True)
         got = ([np.concatenate(outs[k]) for k in range(8)], np.concatenate(aidx), np.concatenate(pidx))
         if full:
