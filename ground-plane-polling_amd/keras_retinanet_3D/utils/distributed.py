@@ -97,6 +97,24 @@ class ShardedModel(object):
         local_planes = planes[lo:hi] if len(planes.shape) == 3 else planes
         plan = self.model.stage_inputs([images[lo:hi], P_inv[lo:hi], local_planes])
         self.model.run_plan(plan)
-        packed = pack_outputs(self.model.outputs(plan))
+        packed = self._packed_shard(plan, hi - lo)
         sizes = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
         return unpack_outputs(gather_detections(packed, sizes, self.group))
+
+    def _packed_shard(self, plan, n_local):
+        """ this rank's (n_local, 100, 35) packed detections.  A dtype='f16x3' model watches the half range here as every synchronous call does
+        (models/retinanet.py `on_range_event`): the counter rides behind the packed shard, is read BEFORE the shard goes on the wire, and a
+        shard whose activations left the range is recomputed on the float32 twin first -- the gathered batch never holds a clamped result. """
+        model = self.model
+        if not (hasattr(model, 'watches_range') and model.watches_range()):
+            return pack_outputs(model.outputs(plan))
+        import torch
+        flat = model.pack_with_range(plan)
+        n = n_local * 100 * PACK_WIDTH
+        count = int(flat[n:].cpu().numpy().view(np.uint64)[0])                       # 8 bytes; the stream has reached the end of this rank's plan
+        if count == model._range_seen:
+            return flat[:n].view(n_local, 100, PACK_WIDTH)
+        model._range_seen = count
+        outs = model._range_event([plan.images, plan.P_inv, plan.planes], 'predict_on_batch')
+        host = np.concatenate([np.asarray(o, np.float32).reshape(n_local, 100, -1) for o in outs], axis=2)
+        return torch.as_tensor(np.ascontiguousarray(host)).to(flat.device)

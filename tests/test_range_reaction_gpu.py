@@ -119,3 +119,17 @@ def test_frame_pipeline_reruns_an_affected_batch_at_float32():
     assert model.range_fallbacks == 3
     for (outs, _), r in zip(got, want):
         assert same(outs, r)
+
+
+def test_a_sharded_call_recomputes_its_shard_before_the_gather():
+    """ utils.distributed.ShardedModel: the rank's shard is checked (and, after an event, recomputed at float32) before it goes on the wire """
+    from keras_retinanet_3D.utils import distributed as D
+    w = scaled_weights()
+    model = models.load_model(w, backbone_name='resnet50', dtype='f16x3')
+    got = D.ShardedModel(model).predict_on_batch(inputs())                # (no process group: one rank holds the whole batch)
+    want = models.load_model(w, backbone_name='resnet50', dtype='f32').predict_on_batch(inputs())
+    assert model.range_fallbacks == 1 and same(got, want)
+    sane = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='f16x3')
+    a = D.ShardedModel(sane).predict_on_batch(inputs())
+    b = sane.predict_on_batch(inputs())
+    assert sane.range_fallbacks == 0 and same(a, b)
