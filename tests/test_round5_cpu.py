@@ -68,3 +68,22 @@ def test_the_trained_weight_family_computes_the_base_function_with_other_statist
     # ... and the heads see (nearly) the base draw's features: only the dead channels change the function
     assert abs(float(b['P3'].std() / a['P3'].std()) - 1.0) < 0.25
     assert float(np.corrcoef(a['classification_logits'].ravel(), b['classification_logits'].ravel())[0, 1]) > 0.8
+
+
+def test_packed_results_with_the_range_counter_behind_them_unpack_on_the_host():
+    """ models/retinanet.py pack_with_range / unpack_with_range: B x 100 x 35 packed detections + the 8 bytes of the f16x3 range counter """
+    from keras_retinanet_3D.models.retinanet import RetinaNet3D
+    from keras_retinanet_3D.utils import distributed as D
+    rng = np.random.default_rng(0)
+    B = 3
+    packed = rng.standard_normal((B, 100, D.PACK_WIDTH)).astype(np.float32)
+    packed[:, :, 16:18] = rng.integers(-1, 4, size=(B, 100, 2))                  # labels, orientations: small integers
+    flat = np.empty((B * 100 * D.PACK_WIDTH + 2,), np.float32)
+    flat[:-2] = packed.ravel()
+    flat[-2:].view(np.uint64)[0] = 123456789012
+    outs, count = RetinaNet3D.unpack_with_range(flat, B)
+    assert count == 123456789012 and len(outs) == 8
+    want = D.unpack_outputs(packed)
+    for a, b in zip(outs, want):
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b) and a.flags.writeable
+    assert outs[3].dtype == np.int32 and outs[5].shape == (B, 100, 4, 3) and outs[6].shape == (B, 100, 1, 4)
