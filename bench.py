@@ -680,13 +680,6 @@ def main():
                          'frac_per_repeat': repeat_fracs or None,
                          'library': version},
         }
-        if getattr(model, 'wino', False):
-            # GPP_WINO=1: the tagged launches are the Winograd F(2, 3) position GEMMs (csrc/conv_wino_impl.h).  `achieved` / `frac` stay the
-            # DIRECT-EQUIVALENT rate (431.8 GFLOP per launch / time) so that the line compares with the direct kernel's; what the matrix pipe
-            # executed is two thirds of it -- a `frac` near the direct peak would not mean skipped work, and this field says so
-            rec['roofline']['executed_mfma_frac'] = round(achieved * 2.0 / 3.0 / PEAK_TFLOPS[args.dtype], 4)
-            rec['roofline']['kernel'] = 'wino_conv_kernel (Winograd F(2,3) along W, 4 position GEMMs per output pair; the input transforms are separate launches, not in this figure) on pyramid_regression_1..3'
-            rec['roofline']['traffic'] = None
         if args.dtype in PIPE_ON_RANDOM_DATA_TFLOPS:
             rec['roofline']['pipe_on_random_data'] = round(PIPE_ON_RANDOM_DATA_TFLOPS[args.dtype], 1)
             rec['roofline']['frac_of_pipe_on_random_data'] = round(achieved / PIPE_ON_RANDOM_DATA_TFLOPS[args.dtype], 4)

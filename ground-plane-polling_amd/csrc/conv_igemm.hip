@@ -136,18 +136,6 @@ extern "C" int gpp_x3_range_snapshot(uint64_t* device_count, void* stream)
     return gpp_x3_range_snapshot_f16x3((unsigned long long*)device_count, (hipStream_t)stream);
 }
 
-extern "C" int gpp_wino_transform_f16x3(const gpp_wino_desc* host_desc, void* stream)
-{
-    if (!host_desc) return GPP_ERR_BAD_ARG;
-    return gpp_wino_transform_dispatch_f16x3(*host_desc, (hipStream_t)stream);
-}
-
-extern "C" int gpp_wino_conv3x3_f16x3(const gpp_wino_desc* host_desc, void* stream)
-{
-    if (!host_desc) return GPP_ERR_BAD_ARG;
-    return gpp_wino_conv_dispatch_f16x3(*host_desc, (hipStream_t)stream);
-}
-
 extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)
 {
     if (!host_desc || !flops) return GPP_ERR_BAD_ARG;

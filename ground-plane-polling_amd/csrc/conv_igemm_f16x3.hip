@@ -2,7 +2,6 @@
 // (float32 storage, three IEEE-half matrix products per float32 product: 11 + 11 significant bits per operand).
 #include "conv_igemm_impl.h"
 #include "conv_igemm_types.h"
-#include "conv_wino_impl.h"      // Winograd F(2, 3) form of the tower layers: this unit's range counter and split helpers
 
 int gpp_conv_dispatch_f16x3(gpp_conv_desc& d, hipStream_t st) { return dispatch<GPP_F16X3>(d, st); }
 

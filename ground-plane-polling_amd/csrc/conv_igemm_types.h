@@ -19,7 +19,5 @@ int gpp_tail_dispatch_f16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows,
 int gpp_x3_range_events_f16x3(unsigned long long* host_count, int reset);
 int gpp_x3_range_snapshot_f16x3(unsigned long long* device_count, hipStream_t st);
 unsigned long long* gpp_x3_range_counter_f16x3();
-int gpp_wino_transform_dispatch_f16x3(const gpp_wino_desc& d, hipStream_t st);
-int gpp_wino_conv_dispatch_f16x3(const gpp_wino_desc& d, hipStream_t st);
 
 #endif

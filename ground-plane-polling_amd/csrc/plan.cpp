@@ -145,12 +145,6 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
             rc = gpp_bottleneck_tail(d->conv3x3, d->conv1x1, d->tile_rows, stream);
             break;
         }
-        case GPP_OP_WINO_TRANSFORM:
-            rc = gpp_wino_transform_f16x3((const gpp_wino_desc*)op.desc, stream);
-            break;
-        case GPP_OP_WINO_CONV:
-            rc = gpp_wino_conv3x3_f16x3((const gpp_wino_desc*)op.desc, stream);
-            break;
         case GPP_OP_RELU: {
             const gpp_relu_desc* d = (const gpp_relu_desc*)op.desc;
             rc = gpp_relu_strided(d->in, d->in_bstride, d->out, d->out_bstride, d->dtype, d->B, d->count, stream);

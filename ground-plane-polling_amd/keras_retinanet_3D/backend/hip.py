@@ -71,21 +71,6 @@ class ConvDesc(ctypes.Structure):
                 ('x3_split', ctypes.c_int32), ('reserved2', ctypes.c_int32), ('out_scale', c_void_p)]
 
 
-class WinoGroup(ctypes.Structure):
-    """ gpp_wino_group (include/gpp.h) """
-    _fields_ = [('H', ctypes.c_int32), ('W', ctypes.c_int32), ('map_off', c_int64), ('pair_off', c_int64)]
-
-
-class WinoDesc(ctypes.Structure):
-    """ gpp_wino_desc (include/gpp.h): the Winograd F(2, 3) form of a 3 x 3 layer on pre-split f16x3 maps (transform + position GEMMs) """
-    _fields_ = [('inp', c_void_p), ('out', c_void_p), ('weight', c_void_p), ('bias', c_void_p), ('out_scale', c_void_p),
-                ('in_bstride', c_int64), ('out_bstride', c_int64),
-                ('batch', ctypes.c_int32), ('C_in', ctypes.c_int32), ('C_out', ctypes.c_int32), ('in_pitch', ctypes.c_int32),
-                ('out_pitch', ctypes.c_int32), ('relu', ctypes.c_int32), ('n_groups', ctypes.c_int32), ('pairs_per_image', ctypes.c_int32),
-                ('in_bytes', ctypes.c_int32), ('weight_bytes', ctypes.c_int32),
-                ('groups', WinoGroup * GPP_MAX_GROUPS)]
-
-
 def _declare(lib):
     lib.gpp_version.restype = ctypes.c_char_p
     lib.gpp_version.argtypes = []
@@ -145,10 +130,6 @@ def _declare(lib):
     lib.gpp_conv2d_tile_candidates.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int)]
     lib.gpp_x3_range_events.restype = c_int
     lib.gpp_x3_range_events.argtypes = [ctypes.POINTER(ctypes.c_uint64), c_int]
-    lib.gpp_wino_transform_f16x3.restype = c_int
-    lib.gpp_wino_transform_f16x3.argtypes = [ctypes.POINTER(WinoDesc), c_void_p]
-    lib.gpp_wino_conv3x3_f16x3.restype = c_int
-    lib.gpp_wino_conv3x3_f16x3.argtypes = [ctypes.POINTER(WinoDesc), c_void_p]
     lib.gpp_x3_range_snapshot.restype = c_int
     lib.gpp_x3_range_snapshot.argtypes = [c_void_p, c_void_p]
     lib.gpp_conv2d_autotune.restype = c_int

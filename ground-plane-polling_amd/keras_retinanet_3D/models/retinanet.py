@@ -84,7 +84,6 @@ OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4,
 OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT = 8, 9, 10
 OP_DETECT_OSF = 12
 OP_STEM_POOL = 13
-OP_WINO_TRANSFORM, OP_WINO_CONV = 14, 15
 DETECT_OPS = (OP_DETECT, OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT, 12)
 OP_JOIN, OP_SYNC = 0x10000, 0x20000
 
@@ -223,10 +222,6 @@ class RetinaNet3D(object):
         W.validate_weights(weights, self.backbone_name)
         self.conv_w = {}
         self.conv_scale = {}
-        # GPP_WINO=1 (dtype='f16x3' only; default off): layers 1 - 3 of the regression tower as Winograd F(2, 3) along W -- 4 matrix products per
-        # output pair instead of 6 -- behind an input-transform launch each (profiles/r5/fastconv_feasibility.md)
-        self.wino = self.dtype == 'f16x3' and os.environ.get('GPP_WINO', '0') != '0'
-        self.wino_w = {}
 
         def put(name, kernel, bias):
             self.conv_w[name] = (C.pack_weight(kernel, self.dtype, dev), torch.as_tensor(bias).to(dev).contiguous(),
@@ -258,8 +253,6 @@ class RetinaNet3D(object):
                 continue
             k, b = W.folded_conv(weights, name)
             put(name, k, b)
-            if self.wino and name in self.WINO_LAYERS:          # the Winograd F(2, 3) form of the layer (csrc/conv_wino_impl.h): position-major weights
-                self.wino_w[name] = C.pack_weight_wino(k, dev)
         k, b = W.fused_regression_outputs(weights)
         put('pyramid_regression_ops', k, b)
         k, b = W.fused_tower_inputs(weights)
@@ -291,30 +284,6 @@ class RetinaNet3D(object):
         plan.io[name] = (inputs, outputs, residuals)          # FMaps per op (introspection: per-layer parity tests)
         plan.io_parts.setdefault(name, []).append((inputs, outputs, residuals))
         plan.touch(d, [Plan.span(f) for f in list(inputs) + list(residuals or [])], [Plan.span(f, 4 if out_f32 else None) for f in outputs])
-
-    WINO_LAYERS = ('pyramid_regression_1', 'pyramid_regression_2', 'pyramid_regression_3')
-
-    def _wino(self, plan, name, inputs, outputs, relu=True, tag=0):
-        """ a 3 x 3 / stride-1 layer over the pyramid as input transform + Winograd position GEMMs (two launches, gpp_wino_desc) """
-        torch = self.torch
-        _, bias, shape = self.conv_w[name]
-        _, _, cin, cout = shape
-        B = inputs[0].B
-        need = B * C.wino_pairs(inputs) * 4 * cin
-        if getattr(plan, 'wino_v', None) is None or plan.wino_v.numel() < need:
-            plan.wino_v = torch.empty((need,), dtype=torch.float32, device=self.device)      # the transformed map: 2 x the layer's input, reused layer after layer
-            plan.keep.append(plan.wino_v)
-        w, scale = self.wino_w[name]
-        dt = C.wino_desc(inputs, None, B, cin, cout, v=plan.wino_v, transform=True)
-        dc = C.wino_desc(None, outputs, B, cin, cout, weight=w, bias=bias, out_scale=scale, relu=relu, v=plan.wino_v)
-        flops = 2.0 * 9 * cin * cout * sum(f.B * f.H * f.W for f in outputs)                   # direct-equivalent (the executed products are 2 / 3 of it)
-        plan.add(OP_WINO_TRANSFORM, dt, name + '/transform')
-        plan.add(OP_WINO_CONV, dc, name, tag=tag, flops=flops)
-        plan.io[name] = (inputs, outputs, None)
-        plan.io_parts.setdefault(name, []).append((inputs, outputs, None))
-        vspan = Plan.span_of(plan.wino_v)
-        plan.touch(dt, [Plan.span(f) for f in inputs], [vspan])
-        plan.touch(dc, [vspan], [Plan.span(f) for f in outputs])
 
     def _tail(self, plan, nm, a, y, shortcut, join=False, lane=0):
         """ branch2b (3x3) + branch2c (1x1, + shortcut, ReLU) of one bottleneck as ONE launch
@@ -531,10 +500,7 @@ class RetinaNet3D(object):
             for i in range(1, 4):
                 _, dst = pyramid(width)
                 name = '{}_{}'.format(prefix, i)
-                if self.wino and name in self.WINO_LAYERS and x3s and lane == 0:
-                    self._wino(plan, name, src, dst, relu=True, tag=tag)
-                else:
-                    self._conv(plan, name, src, dst, 3, pad=(1, 1), relu=True, tag=tag, lane=lane)
+                self._conv(plan, name, src, dst, 3, pad=(1, 1), relu=True, tag=tag, lane=lane)
                 src = dst
             return src
 
@@ -557,7 +523,7 @@ class RetinaNet3D(object):
 
         # GPP_CLS_LANE (default: on for B <= 2): the classification tower (+ the candidate pass behind it) on side lane 2 BESIDE the regression
         # tower instead of in front of it.  At batch 1 a tower launch fields 0.9 - 1.9 rounds of workgroups of one wavefront per SIMD: two
-        # independent chains in flight fill the other half of every SIMD (measured: profiles/r5/b1_plan_variants.json).  `pyramid_regression_ops`
+        # independent chains in flight fill the other half of every SIMD (measured: profiles/r5/b1_latency.json, field `plan_variants`).  `pyramid_regression_ops`
         # joins the lane, so the selection that follows sees the candidate keys; at batch 8 every launch fills the chip on its own (off).
         cls_lane = 2 if (overlap and os.environ.get('GPP_CLS_LANE', '1' if B <= 2 else '0') != '0') else 0
         plan.side_lanes['cls_tower'] = bool(cls_lane)

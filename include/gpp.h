@@ -233,32 +233,6 @@ int gpp_x3_range_events(uint64_t* host_count, int reset);
    float32 (`on_range_event`), so that a clamped activation is never returned as a plausible wrong answer. */
 int gpp_x3_range_snapshot(uint64_t* device_count, void* stream);
 
-/* Winograd F(2, 3) along W for 3 x 3 / stride-1 / pad-1 layers on pre-split GPP_F16X3 maps (csrc/conv_wino_impl.h): 4 position products per output
-   PAIR instead of 6, the kernel rows a direct K loop.  Same Conv2D + bias + ReLU nodes as gpp_conv2d_igemm (the regression tower,
-   /root/reference/keras_retinanet_3D/models/retinanet.py:100-107); results differ from the direct form by float32 rounding only
-   (oracle/fastconv_numerics.py, tests/test_wino_gpu.py).  Two launches per layer, one descriptor type:
-     gpp_wino_transform_f16x3   in = pre-split map (batch, pixels, in_pitch), out = V (batch, pairs_per_image, 4, C_in) pre-split:
-                                per output pair tx of image row y, d_j = in[y][2 tx - 1 + j] (0 outside): V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-     gpp_wino_conv3x3_f16x3     in = V, out = pre-split map (batch, pixels, out_pitch); weight = [C_out rows in the kernels' 32-row interleave]
-                                [4 positions][C_in / 32 chunks][3 kernel rows][32 hi | 32 lo halves] of U_p = sum_kw G[p][kw] g[kh][kw] x 2^k(p, n);
-                                out_scale = [4][C_out] float32 2^-k(p, n); C_out a multiple of 128, C_in of 32
-   groups[g]: level g of the map (H x W, first element `map_off` inside one image of the pixel-major map, first pair `pair_off` inside one
-   image of V); a row of W pixels has (W + 1) / 2 pairs.  The transformed map must stay below 2 GiB. */
-typedef struct gpp_wino_group { int32_t H, W; int64_t map_off, pair_off; } gpp_wino_group;
-typedef struct gpp_wino_desc {
-    const void* in;
-    void* out;
-    const void* weight;
-    const float* bias;
-    const float* out_scale;
-    int64_t in_bstride, out_bstride;   /* float32-sized elements per image of the PIXEL-major map (transform: in; conv: out) */
-    int32_t batch, C_in, C_out, in_pitch, out_pitch, relu, n_groups, pairs_per_image;
-    int32_t in_bytes, weight_bytes;    /* filled in by the library */
-    gpp_wino_group groups[GPP_MAX_GROUPS];
-} gpp_wino_desc;
-int gpp_wino_transform_f16x3(const gpp_wino_desc* host_desc, void* stream);
-int gpp_wino_conv3x3_f16x3(const gpp_wino_desc* host_desc, void* stream);
-
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
 
@@ -399,8 +373,8 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 /* (11: the three-layer tail of round 2, removed in round 3 -- measured slower than its separate launches) */
 #define GPP_OP_DETECT_OSF 12             /* gpp_detect_desc -> gpp_detect_osf_f32 */
 #define GPP_OP_STEM_POOL 13              /* gpp_stem_desc with out = the pooled map -> gpp_stem_pool_fused_mfma */
-#define GPP_OP_WINO_TRANSFORM 14         /* gpp_wino_desc -> gpp_wino_transform_f16x3 */
-#define GPP_OP_WINO_CONV 15              /* gpp_wino_desc -> gpp_wino_conv3x3_f16x3 */
+/* (14, 15: the Winograd F(2, 3) form of the tower layers of round 5 -- built, measured at -2 % of the step, shelved in round 6:
+   tools/experiments/winograd/) */
 /* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
    that forks from the caller's stream at the first op of that lane; `kind | GPP_OP_JOIN` on a lane-0 op makes it wait
    for every open lane (the end of the plan joins too, and so does every error return: a failed gpp_plan_run leaves no forked work

@@ -9,7 +9,10 @@ for p in (os.path.join(ROOT, 'ground-plane-polling_amd'), ROOT):
         sys.path.insert(0, p)
 
 
-GPU_SUITE_BUDGET_S = 600.0      # the driver gives `pytest -m gpu` 900 s on its box; the default selection has to fit with a margin
+# the driver gives `pytest -m gpu` 900 s on its box; the default selection is meant to fit with a margin.  Going over it is REPORTED (the ten
+# slowest tests are named) and changes the exit status only when asked to: GPP_ENFORCE_SUITE_BUDGET=1 (the builder's own collection runs set it),
+# because a green suite on a slower or loaded box, on a cold tune cache or after a first-time library build must stay green
+GPU_SUITE_BUDGET_S = float(os.environ.get('GPP_SUITE_BUDGET_S', '600'))
 
 
 def pytest_addoption(parser):
@@ -50,7 +53,8 @@ _DURATIONS = []
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """ the default GPU selection must stay inside its budget: a suite that outgrows the driver's step limit turns every parity row red """
+    """ the default GPU selection should stay inside its budget (a suite that outgrows the driver's step limit turns every parity row red):
+    over budget -> a warning with the ten slowest tests; a failure only under GPP_ENFORCE_SUITE_BUDGET=1 """
     import time
     marker = session.config.getoption('-m') or ''
     if 'gpu' not in marker or 'not gpu' in marker or session.config.getoption('--run-slow') or 'slow' in marker:
@@ -60,10 +64,12 @@ def pytest_sessionfinish(session, exitstatus):
     elapsed = time.time() - (session.config._gpp_t0 or time.time())
     if elapsed > GPU_SUITE_BUDGET_S:
         worst = sorted(_DURATIONS, reverse=True)[:10]
-        print('\nGPU suite took {:.0f} s, budget {:.0f} s.  Ten slowest:'.format(elapsed, GPU_SUITE_BUDGET_S))
+        enforce = os.environ.get('GPP_ENFORCE_SUITE_BUDGET', '0') == '1'
+        print('\n{}: GPU suite took {:.0f} s, budget {:.0f} s.  Ten slowest:'.format('ERROR' if enforce else 'WARNING', elapsed, GPU_SUITE_BUDGET_S))
         for d, node, when in worst:
             print('  {:7.1f} s  {}  ({})'.format(d, node, when))
-        session.exitstatus = 1
+        if enforce:
+            session.exitstatus = 1
 
 
 @pytest.fixture(scope='session', autouse=True)

@@ -14,8 +14,7 @@ step b1;           python tools/b1_latency.py --n 100 --host-variants --variants
 step b1_floors;    python tools/fill_floor_table.py f16x3 resnet50 1 2>/dev/null > $o/b1_per_layer.txt; tail -1 $o/b1_per_layer.txt
 step profile;      bash tools/profile_bench.sh $o/prof f16x3 > $o/profile_bench.log 2>&1; tail -4 $o/profile_bench.log
 step pmc;          bash tools/pmc_bench.sh $o/pmc f16x3 > $o/pmc_bench.log 2>&1; tail -12 $o/pmc_bench.log
-step wino;         python tools/bench_wino.py 8 20 > $o/bench_wino_b8.txt 2>&1; tail -3 $o/bench_wino_b8.txt | cut -c1-300; python tools/bench_wino.py 1 30 > $o/bench_wino_b1.txt 2>&1
-step ab_wino;      bash tools/ab_env.sh $o/ab_wino.txt 3 - GPP_WINO=1 GPP_CLS_LANE=1 > /dev/null 2>&1; cat $o/ab_wino.txt
+# (the Winograd steps of this script moved with the path: tools/experiments/winograd/)
 python tools/isa_audit.py --json $o/kernel_resources.json | tail -1
 else
 step smoke;        python __graft_entry__.py smoke 2>&1 | tail -1 | cut -c1-300
