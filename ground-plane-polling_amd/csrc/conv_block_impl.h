@@ -1,0 +1,550 @@
+// A whole ResNet bottleneck in ONE launch for the float32-storage x3 types (GPP_F16X3 / GPP_BF16X3) on pre-split maps:
+//     y = relu( W3 * relu( W2 (*) relu( W1 * x + b1 ) + b2 ) + b3 + shortcut )
+// i.e. the 1x1 conv "branch2a" (C_in -> C, stride 1 or 2), the 3x3 conv "branch2b" (C -> C, stride 1, pad 1) and the 1x1 conv "branch2c"
+// (C -> 4C, + shortcut + ReLU) of keras_resnet's bottleneck_2d (the graph instantiated at
+// /root/reference/keras_retinanet_3D/models/resnet.py:88-93, blocks consumed at :102), C = 64 or 128.
+//
+// Why: at float32-sized storage the three layers of a res2 / res3 block move 966 / 590 MB through HBM at B = 8 (x in, a out, a in,
+// b out, b in, x in again as the shortcut, y out) for 552 / 280 MB of x-in / y-out; the two intermediate maps are what this kernel
+// never writes.  bottleneck_tail_x3_kernel (conv_igemm_impl.h) already keeps `b` in LDS; this one keeps `a` there too.
+//
+// One workgroup (8 wavefronts, one per CU: the LDS footprint is ~144 KB) computes a TH x TW tile of output pixels of one image:
+//   phase 1  a-tile = relu(W1 * x + b1) on the tile PLUS its one-pixel halo, (TH+2) x (TW+2) = R1 rows of a GEMM with K = C_in:
+//            x rows and W1 rows stream through a four-deep LDS ring (three K-steps of LDS-DMA in flight: the x rows are first touches
+//            from HBM); the result goes accumulators -> (scale, bias, ReLU, range check, split) -> LDS as the pre-split rows the
+//            unfused layer would have stored; halo pixels outside the image are the 3x3 layer's zero padding: zero rows.
+//            The halo is recomputed by the neighbouring tiles (R1 / (TH TW) = 1.43 x the 2a work, which is 1/4.5 of the block's).
+//   phase 2  b-tile = relu(W2 (*) a-tile + b2): implicit GEMM with the A operand read STRAIGHT from the a-tile in LDS (tap (kh, kw) of
+//            output pixel (ty, tx) is halo row (ty + kh)(TW + 2) + tx + kw), only W2 streams (four-deep ring, L2-hot);
+//            the result goes to LDS the same way (over the a-tile, which is dead by then).
+//   phase 3  y-tile = relu(W3 * b-tile + b3 + shortcut) in 128-channel tiles of W3, shortcut rows prefetched into registers one tile
+//            ahead, 16-byte stores of pre-split rows.
+// Every output element is summed exactly as the three separate launches sum it -- K-steps ascending (32-channel chunk outer, tap inner),
+// hi*wlo, hi*whi, lo*whi per K-step, fma(acc, out_scale, bias), shortcut added as float32(hi) + float32(lo), ReLU, clamp, split -- so the
+// result is BIT-IDENTICAL to gpp_conv2d_igemm x 3 (tests/test_block_gpu.py) and the kernel is a pure scheduling choice of the plan.
+// Range events (GPP_F16X3) are counted once per stored group, for the pixels the tile owns (not for the recomputed halo).
+#ifndef GPP_CONV_BLOCK_IMPL_H_
+#define GPP_CONV_BLOCK_IMPL_H_
+
+#include "conv_igemm_impl.h"
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `stages` x PER of this wavefront's vector-memory operations are outstanding (stages = 0, 1, 2: wave-uniform)
+template <int PER>
+__device__ __forceinline__ void wait_stages(int stages)
+{
+    if (stages >= 2) wait_vmcnt<2 * PER>();
+    else if (stages == 1) wait_vmcnt<PER>();
+    else wait_vmcnt<0>();
+}
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+// clamp + (optionally) count: what x3_range does, with the counting under the caller's control
+template <int DT>
+__device__ __forceinline__ void x3_range_if(float (&v)[8], unsigned long long* counter, bool count)
+{
+    if constexpr (DT == GPP_F16X3) {
+        float c[8];
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            c[e] = X3Half<DT>::clamp(v[e]);
+            changed |= (c[e] != v[e]);
+        }
+        if (__builtin_expect(changed, 0)) {
+            if (count) atomicAdd(counter, 1ull);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c[e] = (fabsf(v[e]) <= 3.402823466e38f) ? c[e] : v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c[e];
+    }
+}
+
+template <int CMID, int TH, int TW>
+struct BlockShape {
+    static constexpr int NW = 8;
+    static constexpr int HWD = TW + 2;                       // halo width
+    static constexpr int R1 = (TH + 2) * HWD;                // halo pixels: rows of the 2a GEMM
+    static constexpr int M2 = TH * TW;                       // output pixels of the tile
+    static constexpr int KC = CMID / 32;                     // 32-channel slabs of the intermediate tiles
+    static constexpr int WN1 = CMID / 32, WM1 = NW / WN1;    // phase 1 / 2: one 32-column pair per wavefront column
+    static constexpr int MF1 = R1 / WM1 / 16;
+    static constexpr int MB2 = M2 / 16;                      // 16-row blocks of the output tile
+    static constexpr int WN2 = WN1, WM2 = WM1;
+    static constexpr int MF2 = (MB2 + WM2 - 1) / WM2;
+    static constexpr int WN3 = 4, WM3 = 2;                   // phase 3: 128-column tiles of W3
+    static constexpr int MF3 = (MB2 + WM3 - 1) / WM3;
+    static constexpr int PA = R1 / 8;                        // 8-row LDS-DMA pieces of an activation slab
+    static constexpr int A_FULL = PA / NW, A_EXTRA = PA - A_FULL * NW;     // pieces every wavefront issues; wavefronts 0 .. A_EXTRA-1 issue one more
+    static constexpr int B_IT1 = CMID / 8 / NW;
+    static constexpr int A1_BYTES = R1 * kRowBytes, STAGE1 = A1_BYTES + CMID * kRowBytes;
+    static constexpr int S1 = 4;                             // phase-1 ring depth (the a-tile's space is free until the phase ends)
+    static constexpr int T1_SLAB = R1 * kRowBytes, T1_BYTES = KC * T1_SLAB;
+    static constexpr int S2 = 4, STAGE2 = CMID * kRowBytes, B_IT2 = CMID / 8 / NW;
+    static constexpr int T2_SLAB = MB2 * 16 * kRowBytes;
+    static constexpr int W3_SLAB = 128 * kRowBytes, W3_IT = 128 / 8 / NW;
+    static constexpr int REGION_B = (S2 * STAGE2 > KC * W3_SLAB) ? S2 * STAGE2 : KC * W3_SLAB;
+    static constexpr int LDS = (S1 * STAGE1 > T1_BYTES + REGION_B) ? S1 * STAGE1 : T1_BYTES + REGION_B;
+    static_assert(CMID == 64 || CMID == 128, "bottleneck width");
+    static_assert(R1 % (16 * WM1) == 0 && R1 % 8 == 0, "halo rows: whole 16-row blocks per wavefront row, whole 8-row pieces");
+    static_assert(M2 % 16 == 0 && HWD % 8 == 0, "tile: whole 16-row blocks; halo width a multiple of 8 (the LDS swizzle key of a tap-shifted row)");
+    static_assert(MB2 >= WM2 * MF2 - 1 && MB2 >= WM3 * MF3 - 1, "at most the last wavefront row is one block short");
+    static_assert(KC * T2_SLAB <= T1_BYTES && LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int DT, int CMID, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2, const gpp_conv_desc d3,
+                                                                      const int tiles_x, const int tiles_y)
+{
+    static_assert(kX3<DT>, "x3 types on pre-split maps");
+    using S = BlockShape<CMID, TH, TW>;
+    using xh8 = typename X3Half<DT>::vec;
+    using half_t = typename X3Half<DT>::half;
+    constexpr bool OSCALE = (DT == GPP_F16X3);
+    constexpr int NW = S::NW, HWD = S::HWD, R1 = S::R1, M2 = S::M2, KC = S::KC;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4, srow = lane >> 3, gchunk = (lane & 7) ^ srow;
+    const gpp_conv_group& G1 = d1.groups[0];
+    const gpp_conv_group& G3 = d3.groups[0];
+    const int H = G1.H_out, W = G1.W_out;                          // the block's output size (2a's output = 2b's = 2c's)
+    unsigned long long* const counter = (unsigned long long*)d3.range_counter;
+
+    // ---- which tile (each XCD owns a contiguous range of tiles: neighbours share their halo columns / rows in that XCD's L2)
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tpi = tiles_x * tiles_y;
+    const int b = tile / tpi, trem = tile - b * tpi;
+    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    const int y0 = tyi * TH, x0 = txi * TW;                        // first output pixel of the tile
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d1.in, 0, d1.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d1.weight, 0, d1.weight_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d2.weight, 0, d2.weight_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d3.weight, 0, d3.weight_bytes, 0x00020000);
+
+    // =============================================================== phase 1: the a-tile (tile + halo) = relu(W1 x + b1)
+    constexpr int A_IT = S::A_FULL + (S::A_EXTRA ? 1 : 0);
+    const bool extra = S::A_EXTRA && wave < S::A_EXTRA;            // this wavefront issues A_IT activation pieces, not A_FULL
+    int a_voff[A_IT];
+    {
+        const int pitch4 = d1.in_pitch * 4, st = d1.stride;
+        const int img = (int)((G1.in_off + (int64_t)b * G1.in_bstride) * 4) + gchunk * 16;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int r = (i * NW + wave) * 8 + srow;              // halo row this lane stages (piece i * NW + wave)
+            a_voff[i] = kOutOfRange;
+            if (r < R1) {
+                const int hy = r / HWD, hx = r - hy * HWD;
+                const int oy = y0 - 1 + hy, ox = x0 - 1 + hx;
+                if ((unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W) a_voff[i] = img + (oy * st * G1.W_in + ox * st) * pitch4;
+            }
+        }
+    }
+    int w1_voff[S::B_IT1];
+#pragma unroll
+    for (int i = 0; i < S::B_IT1; ++i) w1_voff[i] = ((wave * S::B_IT1 + i) * 8 + srow) * d1.C_in * 4 + gchunk * 16;
+    auto issue1 = [&](int buf, int ks) {
+        unsigned char* sa = smem + buf * S::STAGE1;
+        const int so = __builtin_amdgcn_readfirstlane(ks * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < S::A_FULL; ++i) glds16(in_rsrc, a_voff[i], so, sa + (i * NW + wave) * 8 * kRowBytes);
+        if constexpr (S::A_EXTRA > 0) {
+            if (extra) glds16(in_rsrc, a_voff[A_IT - 1], so, sa + (S::A_FULL * NW + wave) * 8 * kRowBytes);
+        }
+#pragma unroll
+        for (int i = 0; i < S::B_IT1; ++i) glds16(w1_rsrc, w1_voff[i], so, sa + S::A1_BYTES + (wave * S::B_IT1 + i) * 8 * kRowBytes);
+    };
+    const int wm1 = wave / S::WN1, wn1 = wave % S::WN1;
+    int a_rd1[2], b_rd1[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int sw = ((h * 4 + fq) ^ (frow & 7)) << 4;
+        a_rd1[h] = (wm1 * (R1 / S::WM1) + frow) * kRowBytes + sw;
+        b_rd1[h] = S::A1_BYTES + (wn1 * 32 + frow) * kRowBytes + sw;
+    }
+    f32x4 acc1[S::MF1][2];
+#pragma unroll
+    for (int i = 0; i < S::MF1; ++i) { acc1[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    {
+        const int nk1 = d1.C_in / 32;
+        int issued = 0;
+#pragma unroll
+        for (int p = 0; p < S::S1 - 1; ++p)
+            if (issued < nk1) { issue1(issued, issued); ++issued; }
+        for (int ks = 0; ks < nk1; ++ks) {
+            const int ahead = issued - ks - 1;                     // stages younger than ks in flight
+            if (extra) wait_stages<A_IT + S::B_IT1>(ahead);
+            else wait_stages<S::A_FULL + S::B_IT1>(ahead);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (issued < nk1) { issue1(issued & (S::S1 - 1), issued); ++issued; }
+            const unsigned char* sb = smem + (ks & (S::S1 - 1)) * S::STAGE1;
+            xh8 ah[S::MF1], al[S::MF1], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < S::MF1; ++i) {
+                ah[i] = *(const xh8*)(sb + a_rd1[0] + i * 16 * kRowBytes);
+                al[i] = *(const xh8*)(sb + a_rd1[1] + i * 16 * kRowBytes);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *(const xh8*)(sb + b_rd1[0] + j * 16 * kRowBytes);
+                bl[j] = *(const xh8*)(sb + b_rd1[1] + j * 16 * kRowBytes);
+            }
+#pragma unroll
+            for (int i = 0; i < S::MF1; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int js = GPP_SERP2(i, j, 2);
+                    acc1[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc1[i][js]);
+                    acc1[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc1[i][js]);
+                }
+#pragma unroll
+            for (int i = 0; i < S::MF1; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc1[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc1[i][js]); }
+        }
+    }
+    // ---- hand-over 1: everyone is done with the ring; the shortcut rows of output tile 0 and the first W2 stages start moving while the
+    // a-tile is written (scale, bias, ReLU, range check, split) as pre-split rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // rows of the output tile this lane finishes in phase 3 (and their shortcut rows): wavefront layout WM3 x WN3
+    const int wm3 = wave / S::WN3, wn3 = wave % S::WN3;
+    const int nrb3 = __builtin_amdgcn_readfirstlane(min(S::MF3, S::MB2 - wm3 * S::MF3));
+    int64_t obase[S::MF3], rbase[S::MF3];
+    bool ok3[S::MF3];
+#pragma unroll
+    for (int i = 0; i < S::MF3; ++i) {
+        const int m = (wm3 * S::MF3 + i) * 16 + frow;
+        const int ty = m / TW, tx = m - ty * TW;
+        const int oy = y0 + ty, ox = x0 + tx;
+        ok3[i] = i < nrb3 && oy < H && ox < W;
+        const int p = ok3[i] ? oy * W + ox : 0;                    // (rows past the end: pixel 0 of the image, a valid address that is never stored to)
+        obase[i] = G3.out_off + (int64_t)b * G3.out_bstride + (int64_t)p * d3.out_pitch;
+        rbase[i] = G3.res_off + (int64_t)b * G3.res_bstride + (int64_t)p * d3.res_pitch;
+    }
+    f32x8 rpre[S::MF3];
+    auto prefetch_res = [&](int t) {
+        const int n = t * 128 + wn3 * 32 + fq * 8;
+#pragma unroll
+        for (int i = 0; i < S::MF3; ++i) {
+            const char* p = x3_addr(d3.residual, rbase[i], n);
+            rpre[i].lo = *(const f32x4*)p;
+            rpre[i].hi = *(const f32x4*)(p + 64);
+        }
+    };
+    prefetch_res(0);
+
+    constexpr int nk2 = 9 * KC;
+    int w2_voff[S::B_IT2];
+#pragma unroll
+    for (int i = 0; i < S::B_IT2; ++i) w2_voff[i] = ((wave * S::B_IT2 + i) * 8 + srow) * (9 * CMID * 4) + gchunk * 16;
+    auto issue2 = [&](int buf, int ks) {
+        const int so = __builtin_amdgcn_readfirstlane(ks * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < S::B_IT2; ++i)
+            glds16(w2_rsrc, w2_voff[i], so, smem + S::T1_BYTES + buf * S::STAGE2 + (wave * S::B_IT2 + i) * 8 * kRowBytes);
+    };
+    int issued2 = 0;
+#pragma unroll
+    for (int p = 0; p < S::S2 - 1; ++p) { issue2(p, p); ++issued2; }
+
+    {
+        const int n = wn1 * 32 + fq * 8;                           // 8 consecutive channels of the a-tile
+        float bias_v[8], scale_v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bias_v[e] = d1.bias ? d1.bias[n + e] : 0.0f;
+            scale_v[e] = (OSCALE && d1.out_scale) ? d1.out_scale[n + e] : 1.0f;
+        }
+        const int piece = (n & 31) >> 3;
+        unsigned char* slab = smem + (n >> 5) * S::T1_SLAB;
+#pragma unroll
+        for (int i = 0; i < S::MF1; ++i) {
+            const int r = wm1 * (R1 / S::WM1) + i * 16 + frow;
+            const int hy = r / HWD, hx = r - hy * HWD;
+            const int oy = y0 - 1 + hy, ox = x0 - 1 + hx;
+            const bool inside = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+            const bool owned = inside && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = e < 4 ? acc1[i][0][e] : acc1[i][1][e - 4];
+                float v;
+                if constexpr (OSCALE) v = __builtin_fmaf(a, scale_v[e], bias_v[e]);
+                else v = a + bias_v[e];
+                if (d1.relu) v = fmaxf(v, 0.0f);
+                v8[e] = inside ? v : 0.0f;                         // outside the image: the 3x3 layer's zero padding
+            }
+            x3_range_if<DT>(v8, counter, owned);
+            xh8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = (half_t)v8[e];
+                l[e] = (half_t)(v8[e] - (float)h[e]);
+            }
+            unsigned char* row = slab + r * kRowBytes;
+            *(xh8*)(row + ((piece ^ (r & 7)) << 4)) = h;
+            *(xh8*)(row + (((4 + piece) ^ (r & 7)) << 4)) = l;
+        }
+    }
+
+    // =============================================================== phase 2: the b-tile = relu(W2 (*) a-tile + b2)
+    const int wm2 = wm1, wn2 = wn1;
+    const int nrb2 = __builtin_amdgcn_readfirstlane(min(S::MF2, S::MB2 - wm2 * S::MF2));
+    int t1off[S::MF2][3][2];                                       // [row block][kw][hi | lo]: byte offset inside a slab of the tap's row, tap row 0
+#pragma unroll
+    for (int i = 0; i < S::MF2; ++i) {
+        const int m = (wm2 * S::MF2 + i) * 16 + frow;
+        const int ty = m / TW, tx = m - ty * TW;
+        const int rr = ty * HWD + tx;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) t1off[i][kw][h] = (rr + kw) * kRowBytes + (((h * 4 + fq) ^ ((rr + kw) & 7)) << 4);
+    }
+    int b_rd2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) b_rd2[h] = S::T1_BYTES + (wn2 * 32 + frow) * kRowBytes + (((h * 4 + fq) ^ (frow & 7)) << 4);
+    f32x4 acc2[S::MF2][2];
+#pragma unroll
+    for (int i = 0; i < S::MF2; ++i) { acc2[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    auto phase2 = [&](auto NRB_) {
+        constexpr int NRB = decltype(NRB_)::value;
+        for (int cc = 0; cc < KC; ++cc) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                const int ks = cc * 9 + tap;
+                wait_stages<S::B_IT2>(issued2 - ks - 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (issued2 < nk2) { issue2(issued2 & (S::S2 - 1), issued2); ++issued2; }
+                const unsigned char* sa = smem + cc * S::T1_SLAB + kh * HWD * kRowBytes;
+                const unsigned char* sb = smem + (ks & (S::S2 - 1)) * S::STAGE2;
+                xh8 ah[NRB], al[NRB], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < NRB; ++i) {
+                    ah[i] = *(const xh8*)(sa + t1off[i][kw][0]);
+                    al[i] = *(const xh8*)(sa + t1off[i][kw][1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *(const xh8*)(sb + b_rd2[0] + j * 16 * kRowBytes);
+                    bl[j] = *(const xh8*)(sb + b_rd2[1] + j * 16 * kRowBytes);
+                }
+#pragma unroll
+                for (int i = 0; i < NRB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int js = GPP_SERP2(i, j, 2);
+                        acc2[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc2[i][js]);
+                        acc2[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc2[i][js]);
+                    }
+#pragma unroll
+                for (int i = 0; i < NRB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc2[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc2[i][js]); }
+            }
+        }
+    };
+    // (the a-tile is visible to everyone behind the first barrier of the loop)
+    if (nrb2 == S::MF2) phase2(IntC<S::MF2>());
+    else phase2(IntC<(S::MF2 > 1 ? S::MF2 - 1 : 1)>());
+
+    // ---- hand-over 2: everyone is done with the a-tile and the W2 ring; W3 tile 0 streams in while the b-tile is written over the a-tile
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int w3_voff[S::W3_IT];
+#pragma unroll
+    for (int i = 0; i < S::W3_IT; ++i) w3_voff[i] = ((wave * S::W3_IT + i) * 8 + srow) * CMID * 4 + gchunk * 16;
+    auto stage_w3 = [&](int t) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int i = 0; i < S::W3_IT; ++i)
+                glds16(w3_rsrc, w3_voff[i], t * 128 * CMID * 4 + kc * kRowBytes,
+                       smem + S::T1_BYTES + kc * S::W3_SLAB + (wave * S::W3_IT + i) * 8 * kRowBytes);
+    };
+    stage_w3(0);
+    {
+        const int n = wn2 * 32 + fq * 8;
+        float bias_v[8], scale_v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bias_v[e] = d2.bias ? d2.bias[n + e] : 0.0f;
+            scale_v[e] = (OSCALE && d2.out_scale) ? d2.out_scale[n + e] : 1.0f;
+        }
+        const int piece = (n & 31) >> 3;
+        unsigned char* slab = smem + (n >> 5) * S::T2_SLAB;
+#pragma unroll
+        for (int i = 0; i < S::MF2; ++i) {
+            if (i < nrb2) {
+                const int m = (wm2 * S::MF2 + i) * 16 + frow;
+                const int ty = m / TW, tx = m - ty * TW;
+                const bool owned = y0 + ty < H && x0 + tx < W;     // (rows of an edge tile that lie outside the image: computed, never stored, not counted)
+                float v8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = e < 4 ? acc2[i][0][e] : acc2[i][1][e - 4];
+                    float v;
+                    if constexpr (OSCALE) v = __builtin_fmaf(a, scale_v[e], bias_v[e]);
+                    else v = a + bias_v[e];
+                    if (d2.relu) v = fmaxf(v, 0.0f);
+                    v8[e] = v;
+                }
+                x3_range_if<DT>(v8, counter, owned);
+                xh8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h[e] = (half_t)v8[e];
+                    l[e] = (half_t)(v8[e] - (float)h[e]);
+                }
+                unsigned char* row = slab + m * kRowBytes;
+                *(xh8*)(row + ((piece ^ (m & 7)) << 4)) = h;
+                *(xh8*)(row + (((4 + piece) ^ (m & 7)) << 4)) = l;
+            }
+        }
+    }
+
+    // =============================================================== phase 3: y-tile = relu(W3 b-tile + b3 + shortcut), 128 channels at a time
+    int a_rd3[2], b_rd3[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int sw = ((h * 4 + fq) ^ (frow & 7)) << 4;
+        a_rd3[h] = (wm3 * S::MF3 * 16 + frow) * kRowBytes + sw;
+        b_rd3[h] = S::T1_BYTES + (wn3 * 32 + frow) * kRowBytes + sw;
+    }
+    const int n3_tiles = d3.C_out / 128;
+    auto phase3 = [&](auto NRB_) {
+        constexpr int NRB = decltype(NRB_)::value;
+        for (int t = 0; t < n3_tiles; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // W3 tile t (and, for t = 0, the b-tile) is in LDS
+            asm volatile("" ::: "memory");
+            f32x4 acc3[NRB][2];
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) { acc3[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc3[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                xh8 ah[NRB], al[NRB], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < NRB; ++i) {
+                    ah[i] = *(const xh8*)(smem + kc * S::T2_SLAB + a_rd3[0] + i * 16 * kRowBytes);
+                    al[i] = *(const xh8*)(smem + kc * S::T2_SLAB + a_rd3[1] + i * 16 * kRowBytes);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *(const xh8*)(smem + kc * S::W3_SLAB + b_rd3[0] + j * 16 * kRowBytes);
+                    bl[j] = *(const xh8*)(smem + kc * S::W3_SLAB + b_rd3[1] + j * 16 * kRowBytes);
+                }
+#pragma unroll
+                for (int i = 0; i < NRB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int js = GPP_SERP2(i, j, 2);
+                        acc3[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc3[i][js]);
+                        acc3[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc3[i][js]);
+                    }
+#pragma unroll
+                for (int i = 0; i < NRB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc3[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc3[i][js]); }
+            }
+            if (t + 1 < n3_tiles) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                      // everyone has read W3 tile t
+                asm volatile("" ::: "memory");
+                stage_w3(t + 1);                                   // streams in under the epilogue below
+            }
+            const int n = t * 128 + wn3 * 32 + fq * 8;
+            float bias_v[8], scale_v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bias_v[e] = d3.bias ? d3.bias[n + e] : 0.0f;
+                scale_v[e] = (OSCALE && d3.out_scale) ? d3.out_scale[n + e] : 1.0f;
+            }
+            float outv[NRB][8];
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = e < 4 ? acc3[i][0][e] : acc3[i][1][e - 4];
+                    if constexpr (OSCALE) outv[i][e] = __builtin_fmaf(a, scale_v[e], bias_v[e]);
+                    else outv[i][e] = a + bias_v[e];
+                }
+                float r[8];
+                x3_unpack<DT>(rpre[i].lo, rpre[i].hi, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) outv[i][e] += r[e];
+            }
+            if (t + 1 < n3_tiles) prefetch_res(t + 1);             // the next tile's shortcut rows: requested before this tile's stores go out
+#pragma unroll
+            for (int i = 0; i < NRB; ++i)
+                if (ok3[i]) finish8_pre<DT>(d3, outv[i], n, obase[i], false, f32x8());
+        }
+    };
+    if (nrb3 == S::MF3) phase3(IntC<S::MF3>());
+    else phase3(IntC<(S::MF3 > 1 ? S::MF3 - 1 : 1)>());
+}
+
+template <int DT, int CMID, int TH, int TW>
+int launch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, hipStream_t st)
+{
+    using S = BlockShape<CMID, TH, TW>;
+    static DeviceOnce once;
+    auto kernel = bottleneck_block_x3_kernel<DT, CMID, TH, TW>;
+    int rc = once.configure(kernel, S::LDS);
+    if (rc != GPP_OK) return rc;
+    const gpp_conv_group& G = d1.groups[0];
+    const int64_t in_elems = G.in_off + (int64_t)(d1.batch - 1) * G.in_bstride + ((int64_t)G.H_in * G.W_in - 1) * d1.in_pitch + d1.C_in;
+    const int64_t w1_bytes = (int64_t)d1.weight_rows * d1.C_in * 4, w2_bytes = (int64_t)d2.weight_rows * 9 * CMID * 4,
+                  w3_bytes = (int64_t)d3.weight_rows * CMID * 4;
+    if (G.in_off < 0 || G.in_bstride < 0 || in_elems * 4 >= (1LL << 31) || w1_bytes >= (1LL << 31) || w2_bytes >= (1LL << 31) || w3_bytes >= (1LL << 31))
+        return GPP_ERR_UNSUPPORTED;
+    d1.in_bytes = (int32_t)(in_elems * 4);
+    d1.weight_bytes = (int32_t)w1_bytes;
+    d2.weight_bytes = (int32_t)w2_bytes;
+    d3.weight_bytes = (int32_t)w3_bytes;
+    const int tiles_x = (G.W_out + TW - 1) / TW, tiles_y = (G.H_out + TH - 1) / TH;
+    const int64_t grid = (int64_t)d1.batch * tiles_x * tiles_y;
+    if (grid >= (1LL << 31)) return GPP_ERR_UNSUPPORTED;
+    kernel<<<dim3((unsigned)grid), dim3(512), S::LDS, st>>>(d1, d2, d3, tiles_x, tiles_y);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GPP_OK : (int)e;
+}
+
+// tile = TH * 100 + TW (0 = the default of the width)
+template <int DT>
+int dispatch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, int tile, hipStream_t st)
+{
+    if (d2.C_in == 128) {
+        switch (tile) {
+            case 0:
+            case 814: return launch_block_x3<DT, 128, 8, 14>(d1, d2, d3, st);
+            default: return GPP_ERR_BAD_ARG;
+        }
+    }
+    return GPP_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+#endif  // GPP_CONV_BLOCK_IMPL_H_

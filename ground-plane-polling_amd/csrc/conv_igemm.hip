@@ -75,8 +75,19 @@ int split_rule(const gpp_conv_desc& d)
     return split < 1 ? 1 : (split > 8 ? 8 : split);
 }
 
+// GPP_F16X3: a launch whose caller named no range counter adds to the library's per-device one
+int fill_range_counter(gpp_conv_desc& d)
+{
+    if (d.dtype != GPP_F16X3) return d.range_counter ? GPP_ERR_BAD_ARG : GPP_OK;
+    if (!d.range_counter) d.range_counter = (uint64_t*)gpp_x3_range_counter_f16x3();
+    if (!d.range_counter) return GPP_ERR_UNSUPPORTED;
+    return ((uintptr_t)d.range_counter & 7) ? GPP_ERR_ALIGN : GPP_OK;
+}
+
 int dispatch_any(gpp_conv_desc& d, hipStream_t st)
 {
+    const int rc = fill_range_counter(d);
+    if (rc != GPP_OK) return rc;
     if (d.split_k == 0) d.split_k = split_rule(d);
     switch (d.dtype) {
         case GPP_BF16: return gpp_conv_dispatch_bf16(d, st);
@@ -106,6 +117,9 @@ int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int t
     if (d2.C_out % 128 != 0 || d2.weight_rows < d2.C_out) return GPP_ERR_UNSUPPORTED;
     if (G1.H_in != G1.H_out || G1.W_in != G1.W_out || G2.H_out != G1.H_out || G2.W_out != G1.W_out || G2.H_in != G1.H_out || G2.W_in != G1.W_out)
         return GPP_ERR_BAD_ARG;
+    rc = fill_range_counter(d1);
+    if (rc == GPP_OK) rc = fill_range_counter(d2);
+    if (rc != GPP_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (d1.dtype) {
         case GPP_BF16: return gpp_tail_dispatch_bf16(d1, d2, tile_rows, st);
@@ -115,7 +129,46 @@ int tail_entry(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int t
     }
 }
 
+int block_entry(const gpp_conv_desc* conv_a, const gpp_conv_desc* conv_b, const gpp_conv_desc* conv_c, int tile, void* stream)
+{
+    if (!conv_a || !conv_b || !conv_c) return GPP_ERR_BAD_ARG;
+    gpp_conv_desc d1 = *conv_a, d2 = *conv_b, d3 = *conv_c;
+    int rc = validate(d1);
+    if (rc == GPP_OK) rc = validate(d2);
+    if (rc == GPP_OK) rc = validate(d3);
+    if (rc != GPP_OK) return rc;
+    const gpp_conv_group &G1 = d1.groups[0], &G2 = d2.groups[0], &G3 = d3.groups[0];
+    // the triple this kernel fuses, on pre-split maps of one x3 type: 1x1 / stride 1 or 2 / C_in -> C; 3x3 / stride 1 / pad 1 / C -> C (C = 64 or 128);
+    // 1x1 / stride 1 / C -> a multiple of 128, + shortcut map of the output's size
+    if (!is_x3(d1.dtype) || d1.dtype != d2.dtype || d1.dtype != d3.dtype) return GPP_ERR_UNSUPPORTED;
+    if (d1.n_groups != 1 || d2.n_groups != 1 || d3.n_groups != 1 || d1.batch != d2.batch || d1.batch != d3.batch) return GPP_ERR_UNSUPPORTED;
+    if (d1.x3_split != (GPP_X3_IN | GPP_X3_OUT) || d2.x3_split != (GPP_X3_IN | GPP_X3_OUT) || d3.x3_split != (GPP_X3_IN | GPP_X3_OUT | GPP_X3_RES))
+        return GPP_ERR_UNSUPPORTED;
+    if (d1.KH != 1 || d1.KW != 1 || d1.pad_top != 0 || d1.pad_left != 0 || d1.residual || d1.out_f32 || d1.split_k > 1) return GPP_ERR_UNSUPPORTED;
+    if (d2.KH != 3 || d2.KW != 3 || d2.stride != 1 || d2.pad_top != 1 || d2.pad_left != 1 || d2.residual || d2.out_f32 || d2.split_k > 1) return GPP_ERR_UNSUPPORTED;
+    if (d3.KH != 1 || d3.KW != 1 || d3.stride != 1 || d3.pad_top != 0 || d3.pad_left != 0 || !d3.residual || d3.out_f32 || d3.split_k > 1) return GPP_ERR_UNSUPPORTED;
+    const int C = d2.C_in;
+    if ((C != 64 && C != 128) || d2.C_out != C || d1.C_out != C || d3.C_in != C || d3.C_out % 128 != 0) return GPP_ERR_UNSUPPORTED;
+    if (d1.weight_rows < C || d2.weight_rows < C || d3.weight_rows < d3.C_out) return GPP_ERR_UNSUPPORTED;
+    if (G1.H_out != (G1.H_in - 1) / d1.stride + 1 || G1.W_out != (G1.W_in - 1) / d1.stride + 1) return GPP_ERR_BAD_ARG;
+    if (G2.H_in != G1.H_out || G2.W_in != G1.W_out || G2.H_out != G1.H_out || G2.W_out != G1.W_out || G3.H_in != G1.H_out || G3.W_in != G1.W_out ||
+        G3.H_out != G1.H_out || G3.W_out != G1.W_out || G3.H_res != G1.H_out || G3.W_res != G1.W_out)
+        return GPP_ERR_BAD_ARG;
+    rc = fill_range_counter(d1);
+    if (rc == GPP_OK) rc = fill_range_counter(d2);
+    if (rc == GPP_OK) rc = fill_range_counter(d3);
+    if (rc != GPP_OK) return rc;
+    if (d1.range_counter != d3.range_counter || d2.range_counter != d3.range_counter) return GPP_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    return d1.dtype == GPP_F16X3 ? gpp_block_dispatch_f16x3(d1, d2, d3, tile, st) : gpp_block_dispatch_bf16x3(d1, d2, d3, tile, st);
+}
+
 }  // namespace
+
+extern "C" int gpp_bottleneck_block(const gpp_conv_desc* conv1x1_a, const gpp_conv_desc* conv3x3_b, const gpp_conv_desc* conv1x1_c, int tile, void* stream)
+{
+    return block_entry(conv1x1_a, conv3x3_b, conv1x1_c, tile, stream);
+}
 
 extern "C" int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream)
 {

@@ -3,6 +3,9 @@
 #include "conv_igemm_impl.h"
 #include "conv_igemm_types.h"
 
+// the library's per-device range-event counter: what a launch adds to when its descriptor names no counter of its own
+__device__ unsigned long long g_x3_range_events = 0;
+
 int gpp_conv_dispatch_f16x3(gpp_conv_desc& d, hipStream_t st) { return dispatch<GPP_F16X3>(d, st); }
 
 int gpp_tail_dispatch_f16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows, hipStream_t st)
@@ -38,9 +41,16 @@ int gpp_x3_range_snapshot_f16x3(unsigned long long* device_count, hipStream_t st
 
 // device address of the counter on the current device (the x3 stem of stem.hip counts into it too: its float32 output map is split --
 // and clamped -- by the first bottleneck's loop, which has no epilogue of its own to count in)
+// (looked up once per device ordinal: every f16x3 launch without a counter of its own asks)
 unsigned long long* gpp_x3_range_counter_f16x3()
 {
+    static std::atomic<unsigned long long*> counter_of_device[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    unsigned long long* c = counter_of_device[dev].load(std::memory_order_acquire);
+    if (c) return c;
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_x3_range_events)) != hipSuccess) return nullptr;
+    counter_of_device[dev].store((unsigned long long*)p, std::memory_order_release);
     return (unsigned long long*)p;
 }

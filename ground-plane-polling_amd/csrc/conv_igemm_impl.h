@@ -194,9 +194,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // can ask whether one occurred --, a non-finite one stays non-finite (hi = x, lo = x - x), as it would in the float32 path; weights are
 // scaled per output channel by a power of two so that both halves are normal halfs (gpp_conv_desc.out_scale undoes it in the epilogue).
 template <int DT> constexpr bool kX3 = (DT == GPP_BF16X3 || DT == GPP_F16X3);
-// GPP_F16X3: how many 8-channel groups an epilogue has stored with at least one value outside the half range (finite beyond +-65504,
-// inf or NaN) since the counter was last reset.  One counter per translation unit; only the GPP_F16X3 unit ever adds to it.
-__device__ __attribute__((unused)) unsigned long long g_x3_range_events = 0;
+// GPP_F16X3: an epilogue that stores an 8-channel group with at least one value outside the half range (finite beyond +-65504, inf or NaN)
+// adds one event to the counter the launch was given (gpp_conv_desc.range_counter: a plan's own 8-byte slot, or -- filled in by the
+// entry points when the caller left it NULL -- the library's per-device counter, conv_igemm_f16x3.hip).
 // every other type: placeholders so that discarded `if constexpr` branches still parse
 template <int DT> struct X3Half {      // primary template
     using half = __bf16;
@@ -221,7 +221,7 @@ template <> struct X3Half<GPP_F16X3> {
 // that holds a value the clamp changed -- or a NaN, which compares unequal to everything -- takes the branch: the event is counted and
 // non-finite values are put back, so that a NaN / inf is still one after the split instead of reading as +-65504.
 template <int DT>
-__device__ __forceinline__ void x3_range(float (&v)[8])
+__device__ __forceinline__ void x3_range(float (&v)[8], unsigned long long* counter)
 {
     if constexpr (DT == GPP_F16X3) {
         float c[8];
@@ -232,7 +232,7 @@ __device__ __forceinline__ void x3_range(float (&v)[8])
             changed |= (c[e] != v[e]);
         }
         if (__builtin_expect(changed, 0)) {
-            atomicAdd(&g_x3_range_events, 1ull);
+            atomicAdd(counter, 1ull);
 #pragma unroll
             for (int e = 0; e < 8; ++e) c[e] = (fabsf(v[e]) <= 3.402823466e38f) ? c[e] : v[e];
         }
@@ -256,11 +256,11 @@ __device__ __forceinline__ void x3_unpack(const f32x4 hi_bits, const f32x4 lo_bi
     for (int e = 0; e < 8; ++e) r[e] = (float)h.b[e] + (float)l.b[e];
 }
 template <int DT>
-__device__ __forceinline__ void x3_store(void* buf, int64_t base, int n, float (&v)[8])
+__device__ __forceinline__ void x3_store(void* buf, int64_t base, int n, float (&v)[8], unsigned long long* counter)
 {
     using half = typename X3Half<DT>::half;
     typename X3Half<DT>::vec h, l;
-    x3_range<DT>(v);
+    x3_range<DT>(v, counter);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float x = v[e];
@@ -306,7 +306,7 @@ __device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], i
     }
     if constexpr (kX3<DT>) {
         if (d.x3_split & GPP_X3_OUT) {                      // (validated: not out_f32, C_out a multiple of 32)
-            x3_store<DT>(d.out, obase, n, v);
+            x3_store<DT>(d.out, obase, n, v, (unsigned long long*)d.range_counter);
             return;
         }
     }
@@ -319,7 +319,7 @@ __device__ __forceinline__ void finish8(const gpp_conv_desc& d, float (&v)[8], i
             for (int e = 0; e < 8 && n + e < d.C_out; ++e) dst[e] = v[e];
         }
     } else {
-        if constexpr (DT == GPP_F16X3) x3_range<DT>(v);   // an activation map kept as float32: checked here, split by its consumers
+        if constexpr (DT == GPP_F16X3) x3_range<DT>(v, (unsigned long long*)d.range_counter);   // an activation map kept as float32: checked here, split by its consumers
         scalar* dst = (scalar*)d.out + obase + n;
         if (full) {
             *(vec8*)dst = Elem<DT>::pack(v);
@@ -358,7 +358,7 @@ __device__ __forceinline__ void finish8_pre(const gpp_conv_desc& d, float (&v)[8
     }
     if constexpr (kX3<DT>) {
         if (d.x3_split & GPP_X3_OUT) {
-            x3_store<DT>(d.out, obase, n, v);
+            x3_store<DT>(d.out, obase, n, v, (unsigned long long*)d.range_counter);
             return;
         }
     }
@@ -367,7 +367,7 @@ __device__ __forceinline__ void finish8_pre(const gpp_conv_desc& d, float (&v)[8
         *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
         *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     } else {
-        if constexpr (DT == GPP_F16X3) x3_range<DT>(v);
+        if constexpr (DT == GPP_F16X3) x3_range<DT>(v, (unsigned long long*)d.range_counter);
         scalar* dst = (scalar*)d.out + obase + n;
         *(vec8*)dst = Elem<DT>::pack(v);
     }
@@ -1828,7 +1828,7 @@ __global__ __launch_bounds__(256, (BM <= 64 ? 3 : 2)) void bottleneck_tail_x3_ke
                     if (d1.relu) v = fmaxf(v, 0.0f);
                     v8[e] = v;
                 }
-                x3_range<DT>(v8);                                     // exactly what x3_store does to the map the unfused layer writes
+                x3_range<DT>(v8, (unsigned long long*)d1.range_counter);      // exactly what x3_store does to the map the unfused layer writes
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     h[e] = (typename X3Half<DT>::half)v8[e];

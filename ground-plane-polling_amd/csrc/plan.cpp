@@ -145,6 +145,11 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
             rc = gpp_bottleneck_tail(d->conv3x3, d->conv1x1, d->tile_rows, stream);
             break;
         }
+        case GPP_OP_BOTTLENECK_BLOCK: {
+            const gpp_block_desc* d = (const gpp_block_desc*)op.desc;
+            rc = gpp_bottleneck_block(d->conv1x1_a, d->conv3x3_b, d->conv1x1_c, d->tile, stream);
+            break;
+        }
         case GPP_OP_RELU: {
             const gpp_relu_desc* d = (const gpp_relu_desc*)op.desc;
             rc = gpp_relu_strided(d->in, d->in_bstride, d->out, d->out_bstride, d->dtype, d->B, d->count, stream);

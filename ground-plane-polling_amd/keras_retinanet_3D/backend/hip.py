@@ -68,7 +68,7 @@ class ConvDesc(ctypes.Structure):
                 ('in_bytes', ctypes.c_int32), ('weight_bytes', ctypes.c_int32),
                 ('partial', c_void_p), ('partial_bytes', c_int64), ('split_k', ctypes.c_int32), ('partial_rows', ctypes.c_int32),
                 ('groups', ConvGroup * GPP_MAX_GROUPS),
-                ('x3_split', ctypes.c_int32), ('reserved2', ctypes.c_int32), ('out_scale', c_void_p)]
+                ('x3_split', ctypes.c_int32), ('reserved2', ctypes.c_int32), ('out_scale', c_void_p), ('range_counter', c_void_p)]
 
 
 def _declare(lib):
@@ -132,6 +132,8 @@ def _declare(lib):
     lib.gpp_x3_range_events.argtypes = [ctypes.POINTER(ctypes.c_uint64), c_int]
     lib.gpp_x3_range_snapshot.restype = c_int
     lib.gpp_x3_range_snapshot.argtypes = [c_void_p, c_void_p]
+    lib.gpp_bottleneck_block.restype = c_int
+    lib.gpp_bottleneck_block.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), c_int, c_void_p]
     lib.gpp_conv2d_autotune.restype = c_int
     lib.gpp_conv2d_autotune.argtypes = [ctypes.POINTER(ConvDesc), c_int, c_void_p, ctypes.POINTER(c_float)]
 

@@ -188,6 +188,9 @@ typedef struct gpp_conv_desc {
     int32_t reserved2;              /* must be 0 */
     const float* out_scale;         /* GPP_F16X3 only (NULL otherwise, and NULL = all ones): per output channel, accumulator *= out_scale[n]
                                        before the bias -- the inverse of the power of two the channel's packed weights were scaled by */
+    uint64_t* range_counter;        /* GPP_F16X3 only: device address of the 8-byte counter this launch adds its range events to (see
+                                       gpp_x3_range_events below) -- a caller that runs several models or streams gives each plan a slot of
+                                       its own and reads THAT (gpp_x3_range_snapshot_of); NULL = the library's per-device counter */
 } gpp_conv_desc;
 #define GPP_X3_IN 1
 #define GPP_X3_OUT 2
@@ -219,6 +222,15 @@ int gpp_conv2d_tile_candidates(const gpp_conv_desc* host_desc, int* tiles, int c
    tile_rows: 0 (= 128), 96, 128 or 160 output pixels per workgroup (the x3 types also 64: three workgroups per CU).  Other shapes,
    and GPP_F32: GPP_ERR_UNSUPPORTED. */
 int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1x1, int tile_rows, void* stream);
+
+/* A WHOLE bottleneck of the same graph in one launch (GPP_F16X3 / GPP_BF16X3 on pre-split maps): "branch2a" (1x1, C_in -> C, stride 1 or 2, + bias
+   + ReLU), "branch2b" (3x3, C -> C, stride 1, pad 1, + bias + ReLU) and "branch2c" (1x1, C -> multiple of 128, + bias + shortcut + ReLU), C = 64 or
+   128; both intermediate maps stay in LDS (a workgroup computes a tile of output pixels and recomputes branch2a on its one-pixel halo).
+   conv1x1_a->out and conv3x3_b->out are not written.  Results are bit-identical to the three gpp_conv2d_igemm launches (same K order and
+   the same epilogue arithmetic per output element).  The shortcut is conv1x1_c->residual: the block's input map (identity blocks) or the map a
+   projection launch wrote.  tile: 0 = the library's choice, TH * 100 + TW = a tile of TH x TW output pixels (gpp_bottleneck_block_tiles lists what a
+   width accepts).  Other shapes / types: GPP_ERR_UNSUPPORTED. */
+int gpp_bottleneck_block(const gpp_conv_desc* conv1x1_a, const gpp_conv_desc* conv3x3_b, const gpp_conv_desc* conv1x1_c, int tile, void* stream);
 
 /* GPP_F16X3 range ledger.  The half type ends at +-65504: an epilogue that stores an activation outside it (a finite value it has to
    clamp, an inf or a NaN) adds one event per 8-channel group to a device-side counter (one per device).  host_count (host pointer,
@@ -373,6 +385,7 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 /* (11: the three-layer tail of round 2, removed in round 3 -- measured slower than its separate launches) */
 #define GPP_OP_DETECT_OSF 12             /* gpp_detect_desc -> gpp_detect_osf_f32 */
 #define GPP_OP_STEM_POOL 13              /* gpp_stem_desc with out = the pooled map -> gpp_stem_pool_fused_mfma */
+#define GPP_OP_BOTTLENECK_BLOCK 16       /* gpp_block_desc -> gpp_bottleneck_block */
 /* (14, 15: the Winograd F(2, 3) form of the tower layers of round 5 -- built, measured at -2 % of the step, shelved in round 6:
    tools/experiments/winograd/) */
 /* Optional concurrency inside a plan: `kind | GPP_OP_LANE(l)` (l = 1, 2) enqueues the op on a library-owned side stream
@@ -409,6 +422,7 @@ typedef struct gpp_poll_desc {
 } gpp_poll_desc;
 
 typedef struct gpp_tail_desc { const gpp_conv_desc* conv3x3; const gpp_conv_desc* conv1x1; int32_t tile_rows, reserved; } gpp_tail_desc;
+typedef struct gpp_block_desc { const gpp_conv_desc* conv1x1_a; const gpp_conv_desc* conv3x3_b; const gpp_conv_desc* conv1x1_c; int32_t tile, reserved; } gpp_block_desc;
 
 typedef struct gpp_plan_op { int32_t kind; int32_t tag; const void* desc; } gpp_plan_op;
 
