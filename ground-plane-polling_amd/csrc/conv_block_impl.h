@@ -46,6 +46,18 @@ __device__ __forceinline__ void wait_stages(int stages)
 
 template <int V> struct IntC { static constexpr int value = V; };
 
+// Diagnostic build only (make variant NAME=blockstamps EXTRA=-DGPP_BLOCK_STAMPS, tools/bench_block.py): wavefront 0 of every workgroup writes the
+// 100 MHz real-time counter at the phase boundaries into a buffer handed in through conv1x1_a->zero_page (8 words per workgroup).  No output
+// depends on it; the production build contains none of it.
+#ifdef GPP_BLOCK_STAMPS
+#define GPP_BSTAMP(k)                                                                                          \
+    do {                                                                                                       \
+        if (wave == 0 && lane == 0) ((unsigned long long*)d1.zero_page)[(int64_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GPP_BSTAMP(k) do { } while (0)
+#endif
+
 // clamp + (optionally) count: what x3_range does, with the counting under the caller's control
 template <int DT>
 __device__ __forceinline__ void x3_range_if(float (&v)[8], unsigned long long* counter, bool count)
@@ -100,9 +112,14 @@ struct BlockShape {
     static_assert(KC * T2_SLAB <= T1_BYTES && LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int DT, int CMID, int TH, int TW>
+// IDENT: an identity block -- the shortcut IS the block's input (same map, stride 1, C_in = 4 C).  Its rows pass through the LDS ring in
+// phase 1 anyway: K-step k of branch2a stages channels 32 k .. 32 k + 31 of every halo pixel, which are the shortcut values of output
+// channels 32 k .. 32 k + 31.  The two wavefronts that will finish those channels in phase 3 copy their 16-byte pieces from the ring into
+// registers there and then (112 - 128 registers per lane by the end of the phase), and the shortcut map is never read a second time: x goes
+// through the fabric once (measured, profiles/r6: 307 -> 157 MB read per res3 block at B = 8).
+template <int DT, int CMID, int TH, int TW, bool IDENT>
 __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2, const gpp_conv_desc d3,
-                                                                      const int tiles_x, const int tiles_y)
+                                                                      const int tiles_x, const int tiles_y, const int stagger_ticks)
 {
     static_assert(kX3<DT>, "x3 types on pre-split maps");
     using S = BlockShape<CMID, TH, TW>;
@@ -132,6 +149,49 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
     const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d2.weight, 0, d2.weight_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d3.weight, 0, d3.weight_bytes, 0x00020000);
 
+    // Stagger: every workgroup runs an HBM-bound phase (x in), a matrix-bound phase that touches no HBM at all, and another HBM-bound phase
+    // (shortcut in, y out).  Workgroups that start together stay in lockstep -- the whole chip waits on HBM, then the whole chip leaves it
+    // idle.  Odd tile rows therefore start `stagger_ticks` (100 MHz) late, once: from then on one half of the CUs computes while the other
+    // half moves bytes.  Timing only: no result depends on it.
+    if (stagger_ticks > 0 && (tyi & 1)) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (unsigned long long)stagger_ticks;
+        while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(32);
+    }
+    // rows of the output tile this lane finishes in phase 3 (and their shortcut rows): wavefront layout WM3 x WN3
+    const int wm3 = wave / S::WN3, wn3 = wave % S::WN3;
+    const int nrb3 = __builtin_amdgcn_readfirstlane(min(S::MF3, S::MB2 - wm3 * S::MF3));
+    int pix3[S::MF3];                                              // pixel index inside the image, -1 = nothing to store
+    int64_t rbase[IDENT ? 1 : S::MF3];
+    int ctr_off[IDENT ? S::MF3 : 1];                               // IDENT: where the pixel's own row sits in a ring stage (hi piece; lo: ^ 64)
+#pragma unroll
+    for (int i = 0; i < S::MF3; ++i) {
+        const int m = (wm3 * S::MF3 + i) * 16 + frow;
+        const int ty = m / TW, tx = m - ty * TW;
+        const int oy = y0 + ty, ox = x0 + tx;
+        const bool ok = i < nrb3 && oy < H && ox < W;
+        pix3[i] = ok ? oy * W + ox : -1;
+        const int p = ok ? oy * W + ox : 0;                        // (rows past the end: pixel 0 of the image, a valid address that is never stored to)
+        if constexpr (IDENT) {
+            const int r = (ty + 1) * HWD + tx + 1;                 // its halo row
+            ctr_off[i] = (i < nrb3 ? r : 0) * kRowBytes + ((fq ^ (r & 7)) << 4);
+        } else {
+            rbase[i] = G3.res_off + (int64_t)b * G3.res_bstride + (int64_t)p * d3.res_pitch;
+        }
+    }
+    constexpr int RT = IDENT ? CMID / 32 : 1;                      // IDENT: 128-channel output tiles whose shortcut rows live in registers (all of them)
+    f32x8 rres[RT][S::MF3];                                        // IDENT: [output tile][row block] raw [8 hi][8 lo] bits; else [0] = the prefetched tile
+    auto prefetch_res = [&](int t) {
+        if constexpr (!IDENT) {
+            const int n = t * 128 + wn3 * 32 + fq * 8;
+#pragma unroll
+            for (int i = 0; i < S::MF3; ++i) {
+                const char* p = x3_addr(d3.residual, rbase[i], n);
+                rres[0][i].lo = *(const f32x4*)p;
+                rres[0][i].hi = *(const f32x4*)(p + 64);
+            }
+        }
+    };
+    GPP_BSTAMP(0);
     // =============================================================== phase 1: the a-tile (tile + halo) = relu(W1 x + b1)
     constexpr int A_IT = S::A_FULL + (S::A_EXTRA ? 1 : 0);
     const bool extra = S::A_EXTRA && wave < S::A_EXTRA;            // this wavefront issues A_IT activation pieces, not A_FULL
@@ -175,7 +235,53 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
     f32x4 acc1[S::MF1][2];
 #pragma unroll
     for (int i = 0; i < S::MF1; ++i) { acc1[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    {
+    auto step1 = [&](int ks) {
+        const unsigned char* sb = smem + (ks & (S::S1 - 1)) * S::STAGE1;
+        xh8 bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bh[j] = *(const xh8*)(sb + b_rd1[0] + j * 16 * kRowBytes);
+            bl[j] = *(const xh8*)(sb + b_rd1[1] + j * 16 * kRowBytes);
+        }
+#pragma unroll
+        for (int i = 0; i < S::MF1; ++i) {
+            const xh8 ah = *(const xh8*)(sb + a_rd1[0] + i * 16 * kRowBytes);
+            const xh8 al = *(const xh8*)(sb + a_rd1[1] + i * 16 * kRowBytes);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int js = GPP_SERP2(i, j, 2);
+                acc1[i][js] = X3Half<DT>::mfma(bl[js], ah, acc1[i][js]);
+                acc1[i][js] = X3Half<DT>::mfma(bh[js], ah, acc1[i][js]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc1[i][js] = X3Half<DT>::mfma(bh[js], al, acc1[i][js]); }
+        }
+    };
+    if constexpr (IDENT) {
+        constexpr int NK1 = 4 * CMID / 32;                         // C_in = 4 C
+        int issued = 0;
+#pragma unroll
+        for (int p = 0; p < S::S1 - 1; ++p) { issue1(issued, issued); ++issued; }
+#pragma unroll
+        for (int ks = 0; ks < NK1; ++ks) {
+            const int ahead = (NK1 - 1 - ks) < (S::S1 - 2) ? (NK1 - 1 - ks) : (S::S1 - 2);
+            if (extra) wait_stages<A_IT + S::B_IT1>(ahead);
+            else wait_stages<S::A_FULL + S::B_IT1>(ahead);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (issued < NK1) { issue1(issued & (S::S1 - 1), issued); ++issued; }
+            if (wn3 == (ks & 3)) {                                 // this stage holds the shortcut values of this wavefront's channels of output tile ks / 4
+                const unsigned char* sb = smem + (ks & (S::S1 - 1)) * S::STAGE1;
+#pragma unroll
+                for (int i = 0; i < S::MF3; ++i) {
+                    rres[ks >> 2][i].lo = *(const f32x4*)(sb + ctr_off[i]);
+                    rres[ks >> 2][i].hi = *(const f32x4*)(sb + (ctr_off[i] ^ 64));
+                }
+            }
+            step1(ks);
+        }
+    } else {
         const int nk1 = d1.C_in / 32;
         int issued = 0;
 #pragma unroll
@@ -189,63 +295,15 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (issued < nk1) { issue1(issued & (S::S1 - 1), issued); ++issued; }
-            const unsigned char* sb = smem + (ks & (S::S1 - 1)) * S::STAGE1;
-            xh8 ah[S::MF1], al[S::MF1], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < S::MF1; ++i) {
-                ah[i] = *(const xh8*)(sb + a_rd1[0] + i * 16 * kRowBytes);
-                al[i] = *(const xh8*)(sb + a_rd1[1] + i * 16 * kRowBytes);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[j] = *(const xh8*)(sb + b_rd1[0] + j * 16 * kRowBytes);
-                bl[j] = *(const xh8*)(sb + b_rd1[1] + j * 16 * kRowBytes);
-            }
-#pragma unroll
-            for (int i = 0; i < S::MF1; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int js = GPP_SERP2(i, j, 2);
-                    acc1[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc1[i][js]);
-                    acc1[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc1[i][js]);
-                }
-#pragma unroll
-            for (int i = 0; i < S::MF1; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc1[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc1[i][js]); }
+            step1(ks);
         }
     }
+    GPP_BSTAMP(1);
     // ---- hand-over 1: everyone is done with the ring; the shortcut rows of output tile 0 and the first W2 stages start moving while the
     // a-tile is written (scale, bias, ReLU, range check, split) as pre-split rows
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-
-    // rows of the output tile this lane finishes in phase 3 (and their shortcut rows): wavefront layout WM3 x WN3
-    const int wm3 = wave / S::WN3, wn3 = wave % S::WN3;
-    const int nrb3 = __builtin_amdgcn_readfirstlane(min(S::MF3, S::MB2 - wm3 * S::MF3));
-    int64_t obase[S::MF3], rbase[S::MF3];
-    bool ok3[S::MF3];
-#pragma unroll
-    for (int i = 0; i < S::MF3; ++i) {
-        const int m = (wm3 * S::MF3 + i) * 16 + frow;
-        const int ty = m / TW, tx = m - ty * TW;
-        const int oy = y0 + ty, ox = x0 + tx;
-        ok3[i] = i < nrb3 && oy < H && ox < W;
-        const int p = ok3[i] ? oy * W + ox : 0;                    // (rows past the end: pixel 0 of the image, a valid address that is never stored to)
-        obase[i] = G3.out_off + (int64_t)b * G3.out_bstride + (int64_t)p * d3.out_pitch;
-        rbase[i] = G3.res_off + (int64_t)b * G3.res_bstride + (int64_t)p * d3.res_pitch;
-    }
-    f32x8 rpre[S::MF3];
-    auto prefetch_res = [&](int t) {
-        const int n = t * 128 + wn3 * 32 + fq * 8;
-#pragma unroll
-        for (int i = 0; i < S::MF3; ++i) {
-            const char* p = x3_addr(d3.residual, rbase[i], n);
-            rpre[i].lo = *(const f32x4*)p;
-            rpre[i].hi = *(const f32x4*)(p + 64);
-        }
-    };
     prefetch_res(0);
 
     constexpr int nk2 = 9 * KC;
@@ -302,19 +360,18 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
         }
     }
 
+    GPP_BSTAMP(2);
     // =============================================================== phase 2: the b-tile = relu(W2 (*) a-tile + b2)
     const int wm2 = wm1, wn2 = wn1;
     const int nrb2 = __builtin_amdgcn_readfirstlane(min(S::MF2, S::MB2 - wm2 * S::MF2));
-    int t1off[S::MF2][3][2];                                       // [row block][kw][hi | lo]: byte offset inside a slab of the tap's row, tap row 0
+    int t1off[S::MF2][3];                                          // [row block][kw]: byte offset inside a slab of the hi piece of the tap's row, tap row 0 (lo: ^ 64)
 #pragma unroll
     for (int i = 0; i < S::MF2; ++i) {
         const int m = (wm2 * S::MF2 + i) * 16 + frow;
         const int ty = m / TW, tx = m - ty * TW;
         const int rr = ty * HWD + tx;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) t1off[i][kw][h] = (rr + kw) * kRowBytes + (((h * 4 + fq) ^ ((rr + kw) & 7)) << 4);
+        for (int kw = 0; kw < 3; ++kw) t1off[i][kw] = (rr + kw) * kRowBytes + ((fq ^ ((rr + kw) & 7)) << 4);
     }
     int b_rd2[2];
 #pragma unroll
@@ -337,29 +394,27 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
                 if (issued2 < nk2) { issue2(issued2 & (S::S2 - 1), issued2); ++issued2; }
                 const unsigned char* sa = smem + cc * S::T1_SLAB + kh * HWD * kRowBytes;
                 const unsigned char* sb = smem + (ks & (S::S2 - 1)) * S::STAGE2;
-                xh8 ah[NRB], al[NRB], bh[2], bl[2];
-#pragma unroll
-                for (int i = 0; i < NRB; ++i) {
-                    ah[i] = *(const xh8*)(sa + t1off[i][kw][0]);
-                    al[i] = *(const xh8*)(sa + t1off[i][kw][1]);
-                }
+                // fragments one row block at a time (the shortcut rows of an identity block sit in 100+ registers by now): per accumulator the
+                // three products keep their order
+                xh8 bh[2], bl[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     bh[j] = *(const xh8*)(sb + b_rd2[0] + j * 16 * kRowBytes);
                     bl[j] = *(const xh8*)(sb + b_rd2[1] + j * 16 * kRowBytes);
                 }
 #pragma unroll
-                for (int i = 0; i < NRB; ++i)
+                for (int i = 0; i < NRB; ++i) {
+                    const xh8 ah = *(const xh8*)(sa + t1off[i][kw]);
+                    const xh8 al = *(const xh8*)(sa + (t1off[i][kw] ^ 64));
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int js = GPP_SERP2(i, j, 2);
-                        acc2[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc2[i][js]);
-                        acc2[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc2[i][js]);
+                        acc2[i][js] = X3Half<DT>::mfma(bl[js], ah, acc2[i][js]);
+                        acc2[i][js] = X3Half<DT>::mfma(bh[js], ah, acc2[i][js]);
                     }
 #pragma unroll
-                for (int i = 0; i < NRB; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc2[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc2[i][js]); }
+                    for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc2[i][js] = X3Half<DT>::mfma(bh[js], al, acc2[i][js]); }
+                }
             }
         }
     };
@@ -367,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
     if (nrb2 == S::MF2) phase2(IntC<S::MF2>());
     else phase2(IntC<(S::MF2 > 1 ? S::MF2 - 1 : 1)>());
 
+    GPP_BSTAMP(3);
     // ---- hand-over 2: everyone is done with the a-tile and the W2 ring; W3 tile 0 streams in while the b-tile is written over the a-tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -423,6 +479,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
         }
     }
 
+    GPP_BSTAMP(4);
     // =============================================================== phase 3: y-tile = relu(W3 b-tile + b3 + shortcut), 128 channels at a time
     int a_rd3[2], b_rd3[2];
 #pragma unroll
@@ -431,10 +488,11 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
         a_rd3[h] = (wm3 * S::MF3 * 16 + frow) * kRowBytes + sw;
         b_rd3[h] = S::T1_BYTES + (wn3 * 32 + frow) * kRowBytes + sw;
     }
-    const int n3_tiles = d3.C_out / 128;
+    const int n3_tiles = IDENT ? RT : d3.C_out / 128;
     auto phase3 = [&](auto NRB_) {
         constexpr int NRB = decltype(NRB_)::value;
-        for (int t = 0; t < n3_tiles; ++t) {
+#pragma unroll
+        for (int t = 0; t < (IDENT ? RT : n3_tiles); ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // W3 tile t (and, for t = 0, the b-tile) is in LDS
@@ -444,29 +502,25 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
             for (int i = 0; i < NRB; ++i) { acc3[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc3[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-                xh8 ah[NRB], al[NRB], bh[2], bl[2];
-#pragma unroll
-                for (int i = 0; i < NRB; ++i) {
-                    ah[i] = *(const xh8*)(smem + kc * S::T2_SLAB + a_rd3[0] + i * 16 * kRowBytes);
-                    al[i] = *(const xh8*)(smem + kc * S::T2_SLAB + a_rd3[1] + i * 16 * kRowBytes);
-                }
+                xh8 bh[2], bl[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     bh[j] = *(const xh8*)(smem + kc * S::W3_SLAB + b_rd3[0] + j * 16 * kRowBytes);
                     bl[j] = *(const xh8*)(smem + kc * S::W3_SLAB + b_rd3[1] + j * 16 * kRowBytes);
                 }
 #pragma unroll
-                for (int i = 0; i < NRB; ++i)
+                for (int i = 0; i < NRB; ++i) {
+                    const xh8 ah = *(const xh8*)(smem + kc * S::T2_SLAB + a_rd3[0] + i * 16 * kRowBytes);
+                    const xh8 al = *(const xh8*)(smem + kc * S::T2_SLAB + a_rd3[1] + i * 16 * kRowBytes);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int js = GPP_SERP2(i, j, 2);
-                        acc3[i][js] = X3Half<DT>::mfma(bl[js], ah[i], acc3[i][js]);
-                        acc3[i][js] = X3Half<DT>::mfma(bh[js], ah[i], acc3[i][js]);
+                        acc3[i][js] = X3Half<DT>::mfma(bl[js], ah, acc3[i][js]);
+                        acc3[i][js] = X3Half<DT>::mfma(bh[js], ah, acc3[i][js]);
                     }
 #pragma unroll
-                for (int i = 0; i < NRB; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc3[i][js] = X3Half<DT>::mfma(bh[js], al[i], acc3[i][js]); }
+                    for (int j = 0; j < 2; ++j) { const int js = GPP_SERP2(i, j, 2); acc3[i][js] = X3Half<DT>::mfma(bh[js], al, acc3[i][js]); }
+                }
             }
             if (t + 1 < n3_tiles) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -491,26 +545,31 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
                     else outv[i][e] = a + bias_v[e];
                 }
                 float r[8];
-                x3_unpack<DT>(rpre[i].lo, rpre[i].hi, r);
+                x3_unpack<DT>(rres[IDENT ? t : 0][i].lo, rres[IDENT ? t : 0][i].hi, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) outv[i][e] += r[e];
             }
-            if (t + 1 < n3_tiles) prefetch_res(t + 1);             // the next tile's shortcut rows: requested before this tile's stores go out
+            if (!IDENT && t + 1 < n3_tiles) prefetch_res(t + 1);   // the next tile's shortcut rows: requested before this tile's stores go out
 #pragma unroll
             for (int i = 0; i < NRB; ++i)
-                if (ok3[i]) finish8_pre<DT>(d3, outv[i], n, obase[i], false, f32x8());
+                if (pix3[i] >= 0) finish8_pre<DT>(d3, outv[i], n, G3.out_off + (int64_t)b * G3.out_bstride + (int64_t)pix3[i] * d3.out_pitch, false, f32x8());
         }
     };
     if (nrb3 == S::MF3) phase3(IntC<S::MF3>());
     else phase3(IntC<(S::MF3 > 1 ? S::MF3 - 1 : 1)>());
+    GPP_BSTAMP(5);
+#ifdef GPP_BLOCK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GPP_BSTAMP(6);
+#endif
 }
 
-template <int DT, int CMID, int TH, int TW>
-int launch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, hipStream_t st)
+template <int DT, int CMID, int TH, int TW, bool IDENT>
+int launch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, int stagger_us, hipStream_t st)
 {
     using S = BlockShape<CMID, TH, TW>;
     static DeviceOnce once;
-    auto kernel = bottleneck_block_x3_kernel<DT, CMID, TH, TW>;
+    auto kernel = bottleneck_block_x3_kernel<DT, CMID, TH, TW, IDENT>;
     int rc = once.configure(kernel, S::LDS);
     if (rc != GPP_OK) return rc;
     const gpp_conv_group& G = d1.groups[0];
@@ -526,7 +585,7 @@ int launch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, hip
     const int tiles_x = (G.W_out + TW - 1) / TW, tiles_y = (G.H_out + TH - 1) / TH;
     const int64_t grid = (int64_t)d1.batch * tiles_x * tiles_y;
     if (grid >= (1LL << 31)) return GPP_ERR_UNSUPPORTED;
-    kernel<<<dim3((unsigned)grid), dim3(512), S::LDS, st>>>(d1, d2, d3, tiles_x, tiles_y);
+    kernel<<<dim3((unsigned)grid), dim3(512), S::LDS, st>>>(d1, d2, d3, tiles_x, tiles_y, stagger_us * 100);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }
@@ -535,10 +594,21 @@ int launch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, hip
 template <int DT>
 int dispatch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, int tile, hipStream_t st)
 {
+    const int stagger_us = tile / 10000;                      // (experiments: tile + 10000 * microseconds the odd tile rows start late)
+    tile %= 10000;
+    if (stagger_us < 0 || stagger_us > 200) return GPP_ERR_BAD_ARG;
+    // an identity block: the shortcut is the very map branch2a reads (same pointer, offsets and pitches), stride 1, C_in = 4 C -- its rows are
+    // taken from the LDS ring (IDENT); tile + 1000 forces the general form (the shortcut read from its map) on such a block (A/B, tests)
+    const gpp_conv_group &G1 = d1.groups[0], &G3 = d3.groups[0];
+    const bool general = tile >= 1000;
+    tile %= 1000;
+    const bool ident = !general && d3.residual == d1.in && G3.res_off == G1.in_off && G3.res_bstride == G1.in_bstride && d3.res_pitch == d1.in_pitch &&
+                       d1.stride == 1 && d1.C_in == 4 * d2.C_in && d3.C_out == d1.C_in;
     if (d2.C_in == 128) {
         switch (tile) {
             case 0:
-            case 814: return launch_block_x3<DT, 128, 8, 14>(d1, d2, d3, st);
+            case 814: return ident ? launch_block_x3<DT, 128, 8, 14, true>(d1, d2, d3, stagger_us, st)
+                                   : launch_block_x3<DT, 128, 8, 14, false>(d1, d2, d3, stagger_us, st);
             default: return GPP_ERR_BAD_ARG;
         }
     }

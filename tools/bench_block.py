@@ -80,6 +80,33 @@ def main():
         torch.cuda.synchronize()
         same = torch.equal(y2.buf.view(torch.int32), y.buf.view(torch.int32))
         print('{}: bytes equal to the three launches: {}'.format(name, same))
+    if os.environ.get('GPP_BLOCK_STAMPS'):
+        # diagnostic library (make variant NAME=blockstamps EXTRA=-DGPP_BLOCK_STAMPS CONV_UNITS=conv_block_x3; GPP_LIB=.../libgpp_hip_blockstamps.so)
+        import numpy as np
+        nwg = 1 << 16
+        stamps = torch.zeros((nwg * 8,), dtype=torch.int64, device='cuda')
+        f[0].zero_page = stamps.data_ptr()
+        for t in tiles:
+            for cold in (False, True):
+                stamps.zero_()
+                if cold:
+                    trash.fill_(1)
+                hip.check(run_block(f[0], f[1], f[2], t), 'block')
+                torch.cuda.synchronize()
+                s = stamps.cpu().numpy().reshape(nwg, 8)
+                s = s[s[:, 0] > 0].astype(np.float64) / 100.0            # us
+                t0 = s[:, 0].min()
+                names = ['phase 1 (2a loop)', 'hand-over 1 (a-tile)', 'phase 2 (2b loop)', 'hand-over 2 (b-tile)', 'phase 3 (2c + stores)', 'store drain']
+                print('tile {} {}: {} workgroups, launch {:.1f} us first start -> last end'.format(t, 'cold' if cold else 'hot', len(s), s[:, 6].max() - t0))
+                for k, nm in enumerate(names):
+                    dt = s[:, k + 1] - s[:, k]
+                    print('   {:24s} median {:6.2f} us   p10 {:6.2f}   p90 {:6.2f}'.format(nm, np.median(dt), np.percentile(dt, 10), np.percentile(dt, 90)))
+                life = s[:, 6] - s[:, 0]
+                print('   {:24s} median {:6.2f} us   p10 {:6.2f}   p90 {:6.2f}'.format('workgroup life', np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
+                starts = np.sort(s[:, 0] - t0)
+                print('   starts: 256th {:.1f} us, 512th {:.1f} us, last {:.1f} us'.format(starts[min(255, len(starts) - 1)], starts[min(511, len(starts) - 1)], starts[-1]))
+        f[0].zero_page = d[0].zero_page
+        return
     for rep in range(2):
         for cold in (False, True):
             row = []
