@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
     const int wm3 = wave / S::WN3, wn3 = wave % S::WN3;
     const int nrb3 = __builtin_amdgcn_readfirstlane(min(S::MF3, S::MB2 - wm3 * S::MF3));
     int pix3[S::MF3];                                              // pixel index inside the image, -1 = nothing to store
-    int64_t rbase[IDENT ? 1 : S::MF3];
+    int64_t rbase[S::MF3];
     int ctr_off[IDENT ? S::MF3 : 1];                               // IDENT: where the pixel's own row sits in a ring stage (hi piece; lo: ^ 64)
 #pragma unroll
     for (int i = 0; i < S::MF3; ++i) {
@@ -174,21 +174,23 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
         if constexpr (IDENT) {
             const int r = (ty + 1) * HWD + tx + 1;                 // its halo row
             ctr_off[i] = (i < nrb3 ? r : 0) * kRowBytes + ((fq ^ (r & 7)) << 4);
-        } else {
-            rbase[i] = G3.res_off + (int64_t)b * G3.res_bstride + (int64_t)p * d3.res_pitch;
         }
+        rbase[i] = G3.res_off + (int64_t)b * G3.res_bstride + (int64_t)p * d3.res_pitch;
     }
-    constexpr int RT = IDENT ? CMID / 32 : 1;                      // IDENT: 128-channel output tiles whose shortcut rows live in registers (all of them)
-    f32x8 rres[RT][S::MF3];                                        // IDENT: [output tile][row block] raw [8 hi][8 lo] bits; else [0] = the prefetched tile
+    // IDENT: the shortcut rows of the first RT 128-channel output tiles live in registers from phase 1 on; the last tile's are fetched from the
+    // map like the general form's (with all four in registers -- 128 per lane -- the compiler spilled 30 of them: the budget is 256 beside
+    // the accumulators and fragments of three matrix phases; three quarters of the re-read is what there is room for)
+    constexpr int N3T = CMID / 32;                                 // output tiles of an identity block (C_out = 4 C)
+    constexpr int RT = IDENT ? N3T - 1 : 0;
+    f32x8 rres[RT > 0 ? RT : 1][S::MF3];                           // [output tile][row block] raw [8 hi][8 lo] bits
+    f32x8 rpre[S::MF3];                                            // the prefetched tile of the general form / the last tile of an identity block
     auto prefetch_res = [&](int t) {
-        if constexpr (!IDENT) {
-            const int n = t * 128 + wn3 * 32 + fq * 8;
+        const int n = t * 128 + wn3 * 32 + fq * 8;
 #pragma unroll
-            for (int i = 0; i < S::MF3; ++i) {
-                const char* p = x3_addr(d3.residual, rbase[i], n);
-                rres[0][i].lo = *(const f32x4*)p;
-                rres[0][i].hi = *(const f32x4*)(p + 64);
-            }
+        for (int i = 0; i < S::MF3; ++i) {
+            const char* p = x3_addr(d3.residual, rbase[i], n);
+            rpre[i].lo = *(const f32x4*)p;
+            rpre[i].hi = *(const f32x4*)(p + 64);
         }
     };
     GPP_BSTAMP(0);
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (issued < NK1) { issue1(issued & (S::S1 - 1), issued); ++issued; }
-            if (wn3 == (ks & 3)) {                                 // this stage holds the shortcut values of this wavefront's channels of output tile ks / 4
+            if ((ks >> 2) < RT && wn3 == (ks & 3)) {               // this stage holds the shortcut values of this wavefront's channels of output tile ks / 4
                 const unsigned char* sb = smem + (ks & (S::S1 - 1)) * S::STAGE1;
 #pragma unroll
                 for (int i = 0; i < S::MF3; ++i) {
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    prefetch_res(0);
+    if constexpr (!IDENT) prefetch_res(0);
 
     constexpr int nk2 = 9 * KC;
     int w2_voff[S::B_IT2];
@@ -488,11 +490,11 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
         a_rd3[h] = (wm3 * S::MF3 * 16 + frow) * kRowBytes + sw;
         b_rd3[h] = S::T1_BYTES + (wn3 * 32 + frow) * kRowBytes + sw;
     }
-    const int n3_tiles = IDENT ? RT : d3.C_out / 128;
+    const int n3_tiles = IDENT ? N3T : d3.C_out / 128;
     auto phase3 = [&](auto NRB_) {
         constexpr int NRB = decltype(NRB_)::value;
 #pragma unroll
-        for (int t = 0; t < (IDENT ? RT : n3_tiles); ++t) {
+        for (int t = 0; t < (IDENT ? N3T : n3_tiles); ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // W3 tile t (and, for t = 0, the b-tile) is in LDS
@@ -545,11 +547,12 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
                     else outv[i][e] = a + bias_v[e];
                 }
                 float r[8];
-                x3_unpack<DT>(rres[IDENT ? t : 0][i].lo, rres[IDENT ? t : 0][i].hi, r);
+                if (IDENT && t < RT) x3_unpack<DT>(rres[t < RT ? t : 0][i].lo, rres[t < RT ? t : 0][i].hi, r);
+                else x3_unpack<DT>(rpre[i].lo, rpre[i].hi, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) outv[i][e] += r[e];
             }
-            if (!IDENT && t + 1 < n3_tiles) prefetch_res(t + 1);   // the next tile's shortcut rows: requested before this tile's stores go out
+            if (t + 1 < n3_tiles && (!IDENT || t + 1 >= RT)) prefetch_res(t + 1);   // the next tile's shortcut rows: requested before this tile's stores go out
 #pragma unroll
             for (int i = 0; i < NRB; ++i)
                 if (pix3[i] >= 0) finish8_pre<DT>(d3, outv[i], n, G3.out_off + (int64_t)b * G3.out_bstride + (int64_t)pix3[i] * d3.out_pitch, false, f32x8());

@@ -185,8 +185,14 @@ extern "C" int gpp_x3_range_events(uint64_t* host_count, int reset)
 
 extern "C" int gpp_x3_range_snapshot(uint64_t* device_count, void* stream)
 {
+    return gpp_x3_range_snapshot_of(nullptr, device_count, stream);
+}
+
+extern "C" int gpp_x3_range_snapshot_of(const uint64_t* counter, uint64_t* device_count, void* stream)
+{
     if (!device_count) return GPP_ERR_BAD_ARG;
-    return gpp_x3_range_snapshot_f16x3((unsigned long long*)device_count, (hipStream_t)stream);
+    if (((uintptr_t)counter | (uintptr_t)device_count) & 7) return GPP_ERR_ALIGN;
+    return gpp_x3_range_snapshot_f16x3((const unsigned long long*)counter, (unsigned long long*)device_count, (hipStream_t)stream);
 }
 
 extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)

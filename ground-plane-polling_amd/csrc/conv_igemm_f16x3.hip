@@ -31,11 +31,12 @@ int gpp_x3_range_events_f16x3(unsigned long long* host_count, int reset)
 }
 
 // the counter's value at this point of the stream, written to device (or device-visible host) memory: no synchronisation
-__global__ void x3_range_snapshot_kernel(unsigned long long* dst) { *dst = g_x3_range_events; }
+// (counter: the caller's slot, or NULL = the library's per-device counter)
+__global__ void x3_range_snapshot_kernel(const unsigned long long* src, unsigned long long* dst) { *dst = src ? *src : g_x3_range_events; }
 
-int gpp_x3_range_snapshot_f16x3(unsigned long long* device_count, hipStream_t st)
+int gpp_x3_range_snapshot_f16x3(const unsigned long long* counter, unsigned long long* device_count, hipStream_t st)
 {
-    hipLaunchKernelGGL(x3_range_snapshot_kernel, dim3(1), dim3(1), 0, st, device_count);
+    hipLaunchKernelGGL(x3_range_snapshot_kernel, dim3(1), dim3(1), 0, st, counter, device_count);
     return (int)hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ int gpp_tail_dispatch_f16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, int tile_rows,
 int gpp_block_dispatch_f16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, int tile, hipStream_t st);
 int gpp_block_dispatch_bf16x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, int tile, hipStream_t st);
 int gpp_x3_range_events_f16x3(unsigned long long* host_count, int reset);
-int gpp_x3_range_snapshot_f16x3(unsigned long long* device_count, hipStream_t st);
+int gpp_x3_range_snapshot_f16x3(const unsigned long long* counter, unsigned long long* device_count, hipStream_t st);
 unsigned long long* gpp_x3_range_counter_f16x3();
 
 #endif

@@ -122,7 +122,7 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
             if (d->dtype == GPP_F32)      // reference-precision path: float32 [147][64] weights, fmaf chain on the vector ALUs
                 rc = gpp_stem_conv7x7_bn_relu(d->in, (const float*)d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
             else if (d->dtype == GPP_F16X3 || d->dtype == GPP_BF16X3)      // float32 output, three half products per float32 product
-                rc = gpp_stem_conv7x7_bn_relu_x3(d->in, d->weight, d->bias, (float*)d->out, d->B, d->H, d->W, stream);
+                rc = gpp_stem_conv7x7_bn_relu_x3_rc(d->in, d->weight, d->bias, (float*)d->out, d->B, d->H, d->W, d->range_counter, stream);
             else
                 rc = gpp_stem_conv7x7_bn_relu_mfma(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
             break;

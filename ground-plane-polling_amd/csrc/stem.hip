@@ -687,7 +687,14 @@ extern "C" int gpp_stem_pack_weights_f16x3(const float* host_weight_147x64, void
 extern "C" int gpp_stem_conv7x7_bn_relu_x3(const float* in, const void* packed_weight_x3, const float* bias, float* out,
                                            int B, int H, int W, void* stream)
 {
+    return gpp_stem_conv7x7_bn_relu_x3_rc(in, packed_weight_x3, bias, out, B, H, W, nullptr, stream);
+}
+
+extern "C" int gpp_stem_conv7x7_bn_relu_x3_rc(const float* in, const void* packed_weight_x3, const float* bias, float* out,
+                                              int B, int H, int W, uint64_t* range_counter, void* stream)
+{
     if (!in || !packed_weight_x3 || !bias || !out || B <= 0 || H <= 0 || W <= 0) return GPP_ERR_BAD_ARG;
+    if ((uintptr_t)range_counter & 7) return GPP_ERR_ALIGN;
     if (((uintptr_t)out | (uintptr_t)packed_weight_x3) & 15) return GPP_ERR_ALIGN;
     constexpr int ROWS = 8;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
@@ -702,13 +709,8 @@ extern "C" int gpp_stem_conv7x7_bn_relu_x3(const float* in, const void* packed_w
         configured.fetch_or(1ull << dev, std::memory_order_release);
     }
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);                           // persistent workgroups, one per CU
-    static std::atomic<unsigned long long*> counter_of_device[64];
-    unsigned long long* counter = counter_of_device[dev].load(std::memory_order_acquire);
-    if (!counter) {
-        counter = gpp_x3_range_counter_f16x3();
-        if (!counter) return GPP_ERR_UNSUPPORTED;
-        counter_of_device[dev].store(counter, std::memory_order_release);
-    }
+    unsigned long long* counter = range_counter ? (unsigned long long*)range_counter : gpp_x3_range_counter_f16x3();   // (the library's: cached per device there)
+    if (!counter) return GPP_ERR_UNSUPPORTED;
     stem_mfma_x3_kernel<ROWS><<<grid, 64 * ROWS, lds, (hipStream_t)stream>>>(in, (const _Float16*)packed_weight_x3, bias, out, B, H, W, Ho, Wo, counter);
     return result();
 }

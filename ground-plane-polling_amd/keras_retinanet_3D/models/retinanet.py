@@ -44,7 +44,7 @@ from . import weights as W
 
 class StemDesc(ctypes.Structure):
     _fields_ = [('inp', ctypes.c_void_p), ('weight', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('out', ctypes.c_void_p),
-                ('dtype', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32)]
+                ('dtype', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('range_counter', ctypes.c_void_p)]
 
 
 class PoolDesc(ctypes.Structure):
@@ -80,7 +80,12 @@ class TailDesc(ctypes.Structure):
     _fields_ = [('conv3x3', ctypes.c_void_p), ('conv1x1', ctypes.c_void_p), ('tile_rows', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class BlockDesc(ctypes.Structure):
+    _fields_ = [('conv1x1_a', ctypes.c_void_p), ('conv3x3_b', ctypes.c_void_p), ('conv1x1_c', ctypes.c_void_p), ('tile', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 OP_STEM, OP_MAXPOOL, OP_CONV, OP_RELU, OP_DETECT, OP_POLL, OP_TAIL = 1, 2, 3, 4, 5, 6, 7
+OP_BLOCK = 16
 OP_DETECT_CANDIDATES, OP_DETECT_SELECT, OP_DETECT_EMIT = 8, 9, 10
 OP_DETECT_OSF = 12
 OP_STEM_POOL = 13
@@ -189,7 +194,6 @@ class RetinaNet3D(object):
         if self.on_range_event not in ('f32', 'raise', 'ignore'):
             raise ValueError("on_range_event must be 'f32', 'raise' or 'ignore', got {!r}".format(self.on_range_event))
         self.range_fallbacks = 0         # calls whose result was replaced (or refused) because of a range event
-        self._range_seen = 0
         self._twin = None
         self._weights = weights if (dtype == 'f16x3' and self.on_range_event == 'f32') else None
         self.class_specific_filter = class_specific_filter
@@ -213,8 +217,6 @@ class RetinaNet3D(object):
         self._load_tune_cache()
         self._upload(weights)
         self.tag_names = []          # filled by the plan builder: names of event-tagged ops
-        if dtype == 'f16x3' and self.on_range_event != 'ignore':
-            self._range_seen = self.x3_range_events()
 
     # ------------------------------------------------------------------ weights
     def _upload(self, weights):
@@ -271,6 +273,8 @@ class RetinaNet3D(object):
             pad = (0, 0)
         d = C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
                         residuals=residuals, dtype=self.dtype, out_f32=out_f32, out_scale=self.conv_scale.get(name))
+        if self.dtype == 'f16x3':         # this plan's own range-event slot (Plan.range_slot): what its launches count no other plan sees
+            d.range_counter = plan.range_slot.data_ptr()
         # split-K partial tiles: the workspace of this op's stream lane is allocated once every op is known (_build)
         plan.conv_descs.append((d, lane))
         plan.ws_need[lane] = max(plan.ws_need.get(lane, 0), C.workspace_bytes(d))
@@ -299,6 +303,21 @@ class RetinaNet3D(object):
         plan.io_parts.setdefault(name, []).append(([a], [y], [shortcut]))
         plan.touch(t, [Plan.span(a), Plan.span(shortcut)], [Plan.span(y)])
 
+    def _block(self, plan, nm, x, a, bmap, y, shortcut, stride=1, join=False, lane=0):
+        """ a whole bottleneck -- branch2a, branch2b, branch2c (+ shortcut, ReLU) -- as ONE launch (gpp_bottleneck_block): neither intermediate map
+        reaches HBM (`a` / `bmap` only lend the descriptors their shapes).  Bit-identical to the three layers. """
+        d1 = self._desc(plan, 'res{}_branch2a'.format(nm), [x], [a], 1, stride=stride, relu=True)
+        d2 = self._desc(plan, 'res{}_branch2b'.format(nm), [a], [bmap], 3, pad=(1, 1), relu=True)
+        d3 = self._desc(plan, 'res{}_branch2c'.format(nm), [bmap], [y], 1, relu=True, residuals=[shortcut])
+        plan.keep += [d1, d2, d3]
+        t = BlockDesc(ctypes.addressof(d1), ctypes.addressof(d2), ctypes.addressof(d3), 0, 0)
+        plan.op_batch[id(t)] = x.B
+        name = 'res{}_branch2a+2b+2c'.format(nm)
+        plan.add(OP_BLOCK, t, name, flops=C.conv_flops(d1) + C.conv_flops(d2) + C.conv_flops(d3), join=join, lane=lane)
+        plan.io[name] = ([x], [y], [shortcut])
+        plan.io_parts.setdefault(name, []).append(([x], [y], [shortcut]))
+        plan.touch(t, [Plan.span(x), Plan.span(shortcut)], [Plan.span(y)])
+
     def _build(self, B, H, Wd, n_planes, planes_batched):
         torch, dev, dt = self.torch, self.device, self.tdtype
         plan = Plan()
@@ -310,6 +329,10 @@ class RetinaNet3D(object):
         half_stages = set(int(v) for v in os.environ.get('GPP_HALF_LANES', '1,2,3').split(',') if v.strip()) if B >= 2 else set()
         br1_lane = os.environ.get('GPP_BR1_LANE', '1') != '0'         # measured +0.4 % on the f16x3 step (same box, alternating)
         plan.conv_descs, plan.ws_need = [], {}
+        # dtype='f16x3': the 8-byte counter every launch of THIS plan adds its range events to (gpp_conv_desc.range_counter, gpp_stem_desc.range_counter),
+        # never reset by anyone but x3_range_events(reset=True) of this model; range_seen = its value when a result of the plan was last fetched
+        plan.range_slot = torch.zeros((1,), dtype=torch.int64, device=dev)
+        plan.range_seen = 0
 
         def fmap(h, w, c, dtype=None):
             f = C.FMap.empty(B, h, w, c, dtype or dt, dev, half=self.dtype if self.dtype in C.X3_TYPES else 'bf16x3')
@@ -337,14 +360,15 @@ class RetinaNet3D(object):
             # 16-bit types: conv1 + bn_conv1 + relu + pool1 in one launch, the (B, H1, W1, 64) conv map is never stored
             # (bit-identical to the two launches: tests/test_stem_gpu.py)
             d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), x.buf.data_ptr(),
-                         C.gpp_storage_dtype(self.dtype), B, H, Wd)
+                         C.gpp_storage_dtype(self.dtype), B, H, Wd, None)
             plan.add(OP_STEM_POOL, d, 'conv1+pool1', flops=2.0 * B * H1 * W1 * 147 * 64)
             plan.touch(d, [Plan.span_of(plan.images)], [Plan.span(x)])
             plan.stem_out = None
         else:
             stem = fmap(H1, W1, 64)
             d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
-                         hip.GPP_F16X3 if getattr(self, 'stem_x3', False) else C.gpp_storage_dtype(self.dtype), B, H, Wd)
+                         hip.GPP_F16X3 if getattr(self, 'stem_x3', False) else C.gpp_storage_dtype(self.dtype), B, H, Wd,
+                         plan.range_slot.data_ptr() if self.dtype == 'f16x3' else None)
             plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
             plan.touch(d, [Plan.span_of(plan.images)], [Plan.span(stem)])
             plan.stem_out = stem
@@ -368,6 +392,10 @@ class RetinaNet3D(object):
             fuse_tail = [v for v in fuse_tail if v == 64] if x3_level >= 2 else []
         elif self.esz == 4:
             fuse_tail = []              # float32 operands: no fused tail
+        # widths whose WHOLE blocks (branch2a + 2b + 2c + shortcut) run as one launch (gpp_bottleneck_block; x3 types on pre-split maps, C = 128).
+        # GPP_FUSE_BLOCK="128" turns it on for res3.  Default off: measured at parity with the three launches in isolation and in the step
+        # (profiles/r6/README.md: half the fabric bytes, the same time -- each phase of the fused workgroup is bound by its own latencies)
+        fuse_block = [int(v) for v in os.environ.get('GPP_FUSE_BLOCK', '').split(',') if v.strip()] if (self.dtype in C.X3_TYPES and x3_level >= 2) else []
 
         def sub(fm, c0, nb):
             return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch, split=fm.split, half=fm.half)
@@ -409,7 +437,11 @@ class RetinaNet3D(object):
                     if side:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=1)
-                    self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True, lane=ln, join=join_halves)
+                    rec['block'] = f in fuse_block and f == 128 and rec['sc'] is None and rec['b'] is not None
+                    if rec['block']:
+                        self._block(plan, nm, xs, a_, sub(rec['b'], c0, nb), y_, xs, join=join_halves, lane=ln)
+                    else:
+                        self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True, lane=ln, join=join_halves)
                     if join_halves:
                         lane_open = False
                     if rec['sc'] is not None and not side:
@@ -417,7 +449,9 @@ class RetinaNet3D(object):
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=ln)
                     elif rec['sc'] is None:
                         sc_ = xs
-                    if rec['b'] is None:
+                    if rec.get('block'):
+                        pass
+                    elif rec['b'] is None:
                         self._tail(plan, nm, a_, y_, sc_, join=side, lane=ln)
                     else:
                         b_ = sub(rec['b'], c0, nb)
@@ -749,14 +783,29 @@ class RetinaNet3D(object):
         return int(tile) in list(tiles[:min(count.value, 64)])
 
     def x3_range_events(self, reset=False):
-        """ dtype='f16x3': how many 8-channel groups the epilogues have stored with a value outside the half range (a finite activation
-        beyond +-65504, which is clamped, or an inf / NaN, which stays one) since the counter was last reset (gpp_x3_range_events; the
-        counter is per device, shared by every f16x3 model on it).  Zero = the type's range altered nothing.  Synchronises. """
-        n = ctypes.c_uint64(0)
-        hip.check(hip.lib().gpp_x3_range_events(ctypes.byref(n), int(bool(reset))), 'gpp_x3_range_events')
+        """ dtype='f16x3': how many 8-channel groups the epilogues of THIS model's plans have stored with a value outside the half range (a finite
+        activation beyond +-65504, which is clamped, or an inf / NaN, which stays one) since the counters were last reset.  Every plan counts
+        into a slot of its own (Plan.range_slot): other models on the device, other plans and their resets do not show here, and a reset here
+        touches nothing of theirs.  Zero = the type's range altered nothing.  Synchronises. """
+        if self.dtype != 'f16x3':
+            return 0
+        self.torch.cuda.synchronize()
+        total = 0
+        for plan in self._plans.values():
+            total += int(plan.range_slot.item())
+            if reset:
+                plan.range_slot.zero_()
+                plan.range_seen = 0
         if reset:
-            self._range_seen = 0
-        return int(n.value)
+            self.torch.cuda.synchronize()
+        return total
+
+    def note_range(self, plan, count):
+        """ count = the plan's counter as a fetched result saw it: True when events happened since the plan's previous fetch """
+        if count == plan.range_seen:
+            return False
+        plan.range_seen = count
+        return True
 
     def plan_for(self, B, H, Wd, n_planes, planes_batched):
         key = (int(B), int(H), int(Wd), int(n_planes), bool(planes_batched))
@@ -822,9 +871,8 @@ class RetinaNet3D(object):
             outs, count = self.unpack_with_range(self.pack_with_range(plan).cpu().numpy(), plan.shape[0])
         else:
             outs = [t.cpu().numpy() for t in self.outputs(plan)]
-            count = int(self.range_snapshot().cpu().view(self.torch.int64).item()) if watch else 0
-        if watch and count != self._range_seen:
-            self._range_seen = count
+            count = int(self.range_snapshot(plan).cpu().view(self.torch.int64).item()) if watch else 0
+        if watch and self.note_range(plan, count):
             return self._range_event([plan.images, plan.P_inv, plan.planes], 'predict_on_batch')
         return outs
 
@@ -832,12 +880,13 @@ class RetinaNet3D(object):
     def watches_range(self):
         return self.dtype == 'f16x3' and self.on_range_event != 'ignore'
 
-    def range_snapshot(self, dst=None):
-        """ enqueue a copy of the device's range-event counter (its value at this point of the current stream) into two float32 words
-        of device memory (gpp_x3_range_snapshot); no synchronisation """
+    def range_snapshot(self, plan, dst=None):
+        """ enqueue a copy of the plan's range-event counter (its value at this point of the current stream) into two float32 words
+        of device memory (gpp_x3_range_snapshot_of); no synchronisation """
         if dst is None:
             dst = self.torch.empty((2,), dtype=self.torch.float32, device=self.device)
-        hip.check(hip.lib().gpp_x3_range_snapshot(ctypes.c_void_p(dst.data_ptr()), hip.stream_ptr()), 'gpp_x3_range_snapshot')
+        hip.check(hip.lib().gpp_x3_range_snapshot_of(ctypes.c_void_p(plan.range_slot.data_ptr()), ctypes.c_void_p(dst.data_ptr()), hip.stream_ptr()),
+                  'gpp_x3_range_snapshot_of')
         return dst
 
     def pack_with_range(self, plan, out=None):
@@ -853,7 +902,7 @@ class RetinaNet3D(object):
         hip.check(hip.lib().gpp_pack_detections(*([hip.ptr(o) for o in outs] + [B, Dn, ctypes.c_void_p(out.data_ptr()), hip.stream_ptr()])),
                   'gpp_pack_detections')
         if self.watches_range():
-            self.range_snapshot(out[n:])
+            self.range_snapshot(plan, out[n:])
         return out
 
     @staticmethod
@@ -872,15 +921,28 @@ class RetinaNet3D(object):
             raise hip.GppError('{}: an activation left the IEEE-half range of dtype=\'f16x3\' (finite beyond +-65504, inf or NaN; '
                                'gpp_x3_range_events): the result would not be the reference\'s -- load the model with dtype=\'f32\' '
                                'or on_range_event=\'f32\''.format(what))
-        if self._twin is None:
-            self._twin = RetinaNet3D(self._weights, backbone_name=self.backbone_name, dtype='f32', nms=self.nms,
-                                     class_specific_filter=self.class_specific_filter, orientation_specific_filter=self.osf,
-                                     name=self.name + '-f32-twin')
+        self.prepare_fallback()
         if what == 'predict_on_frames':          # device_inputs = [frames uint8, P_inv, planes]: preprocessing included
             return self._twin.predict_on_frames(*device_inputs)[0]
         plan = self._twin.stage_inputs(device_inputs)
         self._twin.run_plan(plan)
         return self._twin.fetch(plan)
+
+    def prepare_fallback(self, B=None, H=None, Wd=None, n_planes=None, planes_batched=True):
+        """ on_range_event='f32': build the float32 twin NOW -- its weights upload (a second copy of the weights in HBM) and, when a shape is
+        given, its plan for that shape (buffers + tile tuning: seconds) -- instead of inside the first call whose activations leave the half
+        range, where it would stall a latency-critical predict_on_batch / FramePipeline iteration (and every other rank of a sharded call).
+        Without it the twin is built lazily, at the first event.  The host copy of the weights is dropped once the twin exists. """
+        if self.dtype != 'f16x3' or self.on_range_event != 'f32':
+            return None
+        if self._twin is None:
+            self._twin = RetinaNet3D(self._weights, backbone_name=self.backbone_name, dtype='f32', nms=self.nms,
+                                     class_specific_filter=self.class_specific_filter, orientation_specific_filter=self.osf,
+                                     name=self.name + '-f32-twin')
+            self._weights = None
+        if B is not None:
+            self._twin.plan_for(B, H, Wd, n_planes, planes_batched)
+        return self._twin
 
     def stage_inputs(self, inputs):
         """ Copy [images, P_inv, planes] into the plan's device buffers; returns the plan. """

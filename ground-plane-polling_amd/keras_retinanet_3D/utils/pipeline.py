@@ -103,6 +103,7 @@ class FramePipeline(object):
                 slot['h_packed'].copy_(slot['d_packed'], non_blocking=True)
                 slot['downloaded'].record(self.down_stream)
         slot['scale'] = scale
+        slot['plan'] = plan
 
     def run(self, batches):
         """ Software pipeline over the batches: while batch k is being enqueued (and batches k-1, k-2 run on the GPU), the
@@ -146,9 +147,15 @@ class FramePipeline(object):
             flat = slot['d_packed'].cpu().numpy()
         outs, count = self.model.unpack_with_range(flat, slot['B'])
         m = self.model
-        if m.watches_range() and count != m._range_seen:
-            # an activation of this batch (or of one still in flight behind it: the counter is the device's) left the half range:
-            # the batch is run again at float32 from the slot's own inputs, which nothing has overwritten yet (on_range_event)
-            m._range_seen = count
-            outs = m._range_event([slot['d_frames'], slot['d_pinv'], slot['d_planes']], 'predict_on_frames')
+        if m.watches_range() and m.note_range(slot['plan'], count):
+            # an activation of THIS batch left the half range (the counter is the plan's own and the batches of a pipeline pass through
+            # it in order: whatever it gained since the previous batch's snapshot is this batch's): the batch is run again at float32 from the
+            # slot's own inputs, which nothing has overwritten yet (on_range_event) -- on a stream of its own, so that the float32 run does
+            # not queue up behind the batches already in flight on the compute stream (they keep running beside it)
+            torch = self.torch
+            if getattr(self, 'fallback_stream', None) is None:
+                self.fallback_stream = torch.cuda.Stream(priority=-1)
+            self.fallback_stream.wait_event(slot['uploaded'])
+            with torch.cuda.stream(self.fallback_stream):
+                outs = m._range_event([slot['d_frames'], slot['d_pinv'], slot['d_planes']], 'predict_on_frames')
         return outs, slot['scale']

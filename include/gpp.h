@@ -245,6 +245,12 @@ int gpp_x3_range_events(uint64_t* host_count, int reset);
    float32 (`on_range_event`), so that a clamped activation is never returned as a plausible wrong answer. */
 int gpp_x3_range_snapshot(uint64_t* device_count, void* stream);
 
+/* The same for a counter of the caller's (the slot its descriptors name in gpp_conv_desc.range_counter / gpp_stem_desc.range_counter; NULL = the
+   library's per-device counter).  A caller that runs several GPP_F16X3 models, or one model from several streams, gives every plan its own
+   8-byte slot: what one plan's launches count is then invisible to every other plan -- no spurious reaction, no missed one, whoever resets
+   what (models/retinanet.py: Plan.range_slot). */
+int gpp_x3_range_snapshot_of(const uint64_t* counter, uint64_t* device_count, void* stream);
+
 /* Algorithmic FLOPs (2 * MACs) of one launch described by host_desc. */
 int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops);
 
@@ -281,6 +287,10 @@ int gpp_stem_pool_fused_mfma(const float* in, const void* packed_weight_f16, con
 int gpp_stem_pack_weights_f16x3(const float* host_weight_147x64, void* host_packed, size_t packed_bytes);
 int gpp_stem_conv7x7_bn_relu_x3(const float* in, const void* packed_weight_x3, const float* bias, float* out,
                                 int B, int H, int W, void* stream);
+/* ... counting its range events (output values the half type cannot hold: the map is split -- and clamped -- by the layers that read it) into
+ * the caller's 8-byte slot instead of the library's per-device counter (NULL = that one: the function above) */
+int gpp_stem_conv7x7_bn_relu_x3_rc(const float* in, const void* packed_weight_x3, const float* bias, float* out,
+                                   int B, int H, int W, uint64_t* range_counter, void* stream);
 /* dtype GPP_BF16X3 = a pre-split map (gpp_conv_desc.x3_split): ReLU on the [hi | lo] pairs (count in float32-sized elements, a
    multiple of 32) */
 int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream);
@@ -401,7 +411,8 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 #define GPP_OP_SYNC 0x20000
 
 typedef struct gpp_stem_desc { const float* in; const void* weight; const float* bias; void* out;
-                               int32_t dtype, B, H, W; } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem); GPP_F32: float32 [147][64]; GPP_F16X3: gpp_stem_pack_weights_f16x3 */
+                               int32_t dtype, B, H, W; uint64_t* range_counter; /* GPP_F16X3: see gpp_stem_conv7x7_bn_relu_x3_rc; NULL otherwise */
+                             } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem); GPP_F32: float32 [147][64]; GPP_F16X3: gpp_stem_pack_weights_f16x3 */
 typedef struct gpp_pool_desc { const void* in; void* out; int32_t dtype, B, H, W, C, reserved; } gpp_pool_desc;
 typedef struct gpp_relu_desc { const void* in; void* out; int64_t in_bstride, out_bstride, count;
                                int32_t dtype, B; } gpp_relu_desc;

@@ -133,3 +133,44 @@ def test_a_sharded_call_recomputes_its_shard_before_the_gather():
     a = D.ShardedModel(sane).predict_on_batch(inputs())
     b = sane.predict_on_batch(inputs())
     assert sane.range_fallbacks == 0 and same(a, b)
+
+
+def test_two_models_on_two_streams_only_the_affected_one_falls_back(f32_of_the_base_weights):
+    """ every plan counts its range events into a slot of its own (gpp_conv_desc.range_counter, Plan.range_slot): a model whose activations
+    leave the half range beside a sane one -- interleaved calls on two streams of one device, resets of either -- makes exactly its own
+    calls fall back; the sane model never does, and its counters never move """
+    import torch
+    bad = models.load_model(scaled_weights(), backbone_name='resnet50', dtype='f16x3')
+    sane = models.load_model('synthetic:1234', backbone_name='resnet50', dtype='f16x3')
+    want_bad = models.load_model(scaled_weights(), backbone_name='resnet50', dtype='f32').predict_on_batch(inputs())
+    want_sane = sane.predict_on_batch(inputs())
+    assert sane.range_fallbacks == 0
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for k in range(3):
+        with torch.cuda.stream(s1):
+            plan_bad = bad.stage_inputs(inputs())
+            bad.run_plan(plan_bad)
+        with torch.cuda.stream(s2):
+            plan_sane = sane.stage_inputs(inputs())
+            sane.run_plan(plan_sane)
+        with torch.cuda.stream(s2):
+            got_sane = sane.fetch(plan_sane)
+        with torch.cuda.stream(s1):
+            got_bad = bad.fetch(plan_bad)
+        assert same(got_sane, want_sane) and same(got_bad, want_bad)
+        assert bad.range_fallbacks == k + 1 and sane.range_fallbacks == 0
+        if k == 1:
+            assert bad.x3_range_events(reset=True) > 0         # a reset of one model's counters is invisible to the other
+    assert sane.x3_range_events() == 0 and sane._twin is None
+    assert same(f32_of_the_base_weights, want_bad)
+
+
+def test_the_float32_twin_can_be_built_ahead_of_the_first_event():
+    """ load_model(..., on_range_event='f32') builds its float32 twin inside the first affected call (weights upload, plan, tuning: seconds);
+    prepare_fallback() does that ahead of time, and the host copy of the weights is released once the twin exists """
+    model = models.load_model(scaled_weights(), backbone_name='resnet50', dtype='f16x3')
+    assert model._twin is None and model._weights is not None
+    model.prepare_fallback(B, H, Wd, 100, True)
+    assert model._twin is not None and model._weights is None and (B, H, Wd, 100, True) in model._twin._plans
+    out = model.predict_on_batch(inputs())
+    assert model.range_fallbacks == 1 and int((out[2] > 0.05).sum()) > 0
