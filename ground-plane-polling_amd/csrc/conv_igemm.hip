@@ -24,6 +24,11 @@ int validate(const gpp_conv_desc& d)
     if (d.dtype != GPP_BF16 && d.dtype != GPP_F16 && d.dtype != GPP_F32 && !is_x3(d.dtype)) return GPP_ERR_UNSUPPORTED;
     const int esz = elem_size(d.dtype), ck = 128 / esz, va = 16 / esz;     // channels per K-step, elements per 16 bytes
     if (d.batch <= 0 || d.C_in <= 0 || d.C_out <= 0 || d.KH <= 0 || d.KW <= 0) return GPP_ERR_BAD_ARG;
+    // sizes beyond anything a 2 GiB map can hold: refused here, so that the 64-bit size arithmetic below and in the launchers cannot overflow
+    constexpr int kMaxDim = 1 << 20;
+    if (d.batch > kMaxDim || d.C_in > kMaxDim || d.C_out > kMaxDim || d.in_pitch > kMaxDim || d.out_pitch > kMaxDim || d.res_pitch > kMaxDim ||
+        d.weight_rows > kMaxDim || d.weight_rows < 0 || d.in_pitch < 0 || d.out_pitch < 0 || d.res_pitch < 0 || d.partial_bytes < 0)
+        return GPP_ERR_UNSUPPORTED;
     if (d.KH > 8 || d.KW > 8) return GPP_ERR_UNSUPPORTED;           // tap validity masks are 8 + 8 bits
     if (d.C_in % ck != 0 || d.C_out % 4 != 0) return GPP_ERR_UNSUPPORTED;
     if (d.stride != 1 && d.stride != 2) return GPP_ERR_UNSUPPORTED;
@@ -48,6 +53,11 @@ int validate(const gpp_conv_desc& d)
     for (int g = 0; g < d.n_groups; ++g) {
         const gpp_conv_group& G = d.groups[g];
         if (G.H_in <= 0 || G.W_in <= 0 || G.H_out <= 0 || G.W_out <= 0) return GPP_ERR_BAD_ARG;
+        if (G.H_in > kMaxDim || G.W_in > kMaxDim || G.H_out > kMaxDim || G.W_out > kMaxDim || G.H_res > kMaxDim || G.W_res > kMaxDim) return GPP_ERR_UNSUPPORTED;
+        constexpr int64_t kMaxOff = (int64_t)1 << 40;              // element offsets / image strides: far beyond any real buffer, far below overflow
+        if (G.in_off < 0 || G.out_off < 0 || G.res_off < 0 || G.in_bstride < 0 || G.out_bstride < 0 || G.res_bstride < 0 || G.in_off > kMaxOff ||
+            G.out_off > kMaxOff || G.res_off > kMaxOff || G.in_bstride > kMaxOff || G.out_bstride > kMaxOff || G.res_bstride > kMaxOff)
+            return GPP_ERR_BAD_ARG;
         if ((G.out_off | G.out_bstride) % oa != 0) return GPP_ERR_ALIGN;
         if ((G.in_off | G.in_bstride) % va != 0) return GPP_ERR_ALIGN;
         if (d.residual && ((G.res_off | G.res_bstride) % va != 0 || G.H_res <= 0 || G.W_res <= 0)) return GPP_ERR_ALIGN;
@@ -198,6 +208,7 @@ extern "C" int gpp_x3_range_snapshot_of(const uint64_t* counter, uint64_t* devic
 extern "C" int gpp_conv2d_flops(const gpp_conv_desc* host_desc, double* flops)
 {
     if (!host_desc || !flops) return GPP_ERR_BAD_ARG;
+    if (host_desc->n_groups < 1 || host_desc->n_groups > GPP_MAX_GROUPS) return GPP_ERR_BAD_ARG;
     double f = 0.0;
     for (int g = 0; g < host_desc->n_groups; ++g)
         f += 2.0 * host_desc->batch * (double)host_desc->groups[g].H_out * host_desc->groups[g].W_out *
@@ -306,7 +317,13 @@ static bool tile_is_candidate(const gpp_conv_desc* desc, int tile)
 
 extern "C" int gpp_conv2d_tile_candidates(const gpp_conv_desc* desc, int* tiles, int capacity, int* count)
 {
-    if (!desc || !count || (capacity > 0 && !tiles)) return GPP_ERR_BAD_ARG;
+    if (!desc || !count || capacity < 0 || (capacity > 0 && !tiles)) return GPP_ERR_BAD_ARG;
+    {
+        gpp_conv_desc d = *desc;
+        for (int g = 0; g < GPP_MAX_GROUPS; ++g) d.groups[g].row_begin = 0;
+        const int rc = validate(d);
+        if (rc != GPP_OK) return rc;
+    }
     int n = 0;
     for (int tile : kTiles) {
         if (!tile_is_candidate(desc, tile)) continue;
@@ -325,6 +342,12 @@ extern "C" int gpp_conv2d_tile_candidates(const gpp_conv_desc* desc, int* tiles,
 extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream, float* best_us)
 {
     if (!desc || iters < 1) return GPP_ERR_BAD_ARG;
+    {
+        gpp_conv_desc d = *desc;
+        for (int g = 0; g < GPP_MAX_GROUPS; ++g) d.groups[g].row_begin = 0;
+        const int rc = validate(d);
+        if (rc != GPP_OK) return rc;
+    }
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);

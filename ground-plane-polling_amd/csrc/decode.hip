@@ -622,6 +622,10 @@ inline int64_t pow2_ceil(int64_t v)
 
 namespace {
 
+// (beyond these the workspace arithmetic would overflow long before any buffer could exist: 2^28 anchors are 2 000 images' worth)
+constexpr int kMaxBatch = 1 << 16;
+constexpr int64_t kMaxAnchors = (int64_t)1 << 28;
+
 size_t detect_bytes(int B, int64_t n_anchors, int lists_per_image)
 {
     const size_t keys = (size_t)pow2_ceil(n_anchors) * 8;
@@ -643,7 +647,7 @@ int detect_impl(int stages, int lists_per_image, const float* cls_logits, const 
                 int32_t* anchor_index, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (stages <= 0 || stages > 7) return GPP_ERR_BAD_ARG;
-    if (B < 0 || n_anchors <= 0 || max_det <= 0 || max_det > 128 || num_base_anchors <= 0) return GPP_ERR_BAD_ARG;
+    if (B < 0 || B > kMaxBatch || n_anchors <= 0 || n_anchors > kMaxAnchors || max_det <= 0 || max_det > 128 || num_base_anchors <= 0) return GPP_ERR_BAD_ARG;
     if (n_anchors >= (1LL << 31) || n_anchors % num_base_anchors != 0) return GPP_ERR_UNSUPPORTED;
     if (B == 0) return GPP_OK;
     if (!cls_logits || !regression || !regression_dim || !anchors || !boxes || !dims || !scores || !labels ||
@@ -745,14 +749,14 @@ extern "C" int gpp_pack_detections(const float* boxes, const float* dims, const 
 
 extern "C" int gpp_detect_workspace_bytes(int B, int64_t n_anchors, size_t* bytes)
 {
-    if (!bytes || B < 0 || n_anchors <= 0) return GPP_ERR_BAD_ARG;
+    if (!bytes || B < 0 || B > kMaxBatch || n_anchors <= 0 || n_anchors > kMaxAnchors) return GPP_ERR_BAD_ARG;
     *bytes = detect_bytes(B, n_anchors, 1);
     return GPP_OK;
 }
 
 extern "C" int gpp_detect_osf_workspace_bytes(int B, int64_t n_anchors, size_t* bytes)
 {
-    if (!bytes || B < 0 || n_anchors <= 0) return GPP_ERR_BAD_ARG;
+    if (!bytes || B < 0 || B > kMaxBatch || n_anchors <= 0 || n_anchors > kMaxAnchors) return GPP_ERR_BAD_ARG;
     *bytes = detect_bytes(B, n_anchors, 4);
     return GPP_OK;
 }
