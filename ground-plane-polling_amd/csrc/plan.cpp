@@ -3,6 +3,8 @@
 // launches as calling those entry points one by one from the host language.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -52,6 +54,31 @@ struct Lanes {
 };
 Lanes g_lanes_of_device[kMaxDevices];
 
+// GPP_ROCTX=1: a roctx range per stage of the plan (GPP_OP_STAGE: stem, backbone, FPN, heads, decode, polling) around the launches that
+// gpp_plan_run enqueues for it, so that `rocprofv3 --marker-trace --kernel-trace` gives the per-stage split of a step without
+// matching kernel names.  The marker library is looked up at run time (librocprofiler-sdk-roctx.so, the one rocprofv3 listens to; libroctx64.so
+// as a fallback): the library has no link-time dependency on it, and without the variable nothing is loaded and a plan run pays one branch.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("GPP_ROCTX");
+        if (!e || e[0] != '1') return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+const char* const kStageNames[16] = {nullptr, "gpp:stem", "gpp:backbone", "gpp:fpn", "gpp:heads", "gpp:decode", "gpp:polling", "gpp:gather",
+                                     "gpp:stage8", "gpp:stage9", "gpp:stage10", "gpp:stage11", "gpp:stage12", "gpp:stage13", "gpp:stage14", "gpp:stage15"};
+
 }  // namespace
 
 extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, void* const* events, int n_events)
@@ -85,10 +112,20 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
         }
         return first;
     };
-    auto fail = [&](int rc) -> int { (void)close_lanes(); return rc; };
+    static const Roctx roctx;
+    int stage_open = 0;
+    auto set_stage = [&](int s) {
+        if (!roctx.push || s == stage_open) return;
+        if (stage_open) (void)roctx.pop();
+        if (s) (void)roctx.push(kStageNames[s]);
+        stage_open = s;
+    };
+    auto fail = [&](int rc) -> int { set_stage(0); (void)close_lanes(); return rc; };
     for (int i = 0; i < n_ops; ++i) {
         gpp_plan_op op = ops[i];
         if (!op.desc) return fail(GPP_ERR_BAD_ARG);
+        set_stage((op.kind >> 20) & 15);
+        op.kind &= 0xfffff;
         const int lane = (op.kind >> 8) & 0xff;
         const bool join = (op.kind & GPP_OP_JOIN) != 0, sync = (op.kind & GPP_OP_SYNC) != 0;
         op.kind &= 0xff;
@@ -199,6 +236,7 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
             ev += 2;
         }
     }
+    set_stage(0);
     return close_lanes();                               // a plan may not end inside a side lane
 }
 

@@ -170,10 +170,25 @@ class Plan(object):
             seen.append((pos, lane, name, reads, writes))
         return bad
 
+    @staticmethod
+    def stage_of(kind, name):
+        """ include/gpp.h GPP_OP_STAGE: 1 stem, 2 backbone, 3 FPN, 4 heads, 5 decode, 6 polling (roctx ranges under GPP_ROCTX=1) """
+        if kind in (OP_STEM, OP_MAXPOOL, OP_STEM_POOL):
+            return 1
+        if kind in DETECT_OPS:
+            return 5
+        if kind == OP_POLL:
+            return 6
+        if name.startswith('res'):
+            return 2
+        if name.startswith('pyramid_'):
+            return 4
+        return 3                                  # C5_reduced ... P3, P6, C6_relu, P7
+
     def finalize(self):
         arr = (PlanOp * len(self.ops))()
-        for i, (kind, tag, desc, _, _) in enumerate(self.ops):
-            arr[i].kind, arr[i].tag, arr[i].desc = kind | self.lanes[i], tag, ctypes.addressof(desc)
+        for i, (kind, tag, desc, name, _) in enumerate(self.ops):
+            arr[i].kind, arr[i].tag, arr[i].desc = kind | self.lanes[i] | (self.stage_of(kind, name) << 20), tag, ctypes.addressof(desc)
         self.array = arr
 
 

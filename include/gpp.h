@@ -410,6 +410,17 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 /* on a side-lane op: the lane first waits for everything enqueued on the caller's stream so far (a second fork point) */
 #define GPP_OP_SYNC 0x20000
 
+/* Optional stage label of an op, bits 20-23 of `kind`: with GPP_ROCTX=1 in the environment gpp_plan_run opens a roctx range ("gpp:stem", "gpp:backbone",
+   "gpp:fpn", "gpp:heads", "gpp:decode", "gpp:polling") around each run of consecutive ops with the same label (rocprofv3 --marker-trace); 0 = none.
+   The marker library is looked up at run time; without the variable nothing is loaded. */
+#define GPP_OP_STAGE(s) (((s) & 15) << 20)
+#define GPP_STAGE_STEM 1
+#define GPP_STAGE_BACKBONE 2
+#define GPP_STAGE_FPN 3
+#define GPP_STAGE_HEADS 4
+#define GPP_STAGE_DECODE 5
+#define GPP_STAGE_POLLING 6
+
 typedef struct gpp_stem_desc { const float* in; const void* weight; const float* bias; void* out;
                                int32_t dtype, B, H, W; uint64_t* range_counter; /* GPP_F16X3: see gpp_stem_conv7x7_bn_relu_x3_rc; NULL otherwise */
                              } gpp_stem_desc;   /* weight: packed f16 image (MFMA stem); GPP_F32: float32 [147][64]; GPP_F16X3: gpp_stem_pack_weights_f16x3 */

@@ -72,6 +72,16 @@ def pytest_sessionfinish(session, exitstatus):
             session.exitstatus = 1
 
 
+def pytest_terminal_summary(terminalreporter):
+    """ the parity margins the full-size ledger tests measured, in the log itself (a passed test prints nothing otherwise) """
+    mod = sys.modules.get('test_fullsize_golden_gpu')
+    lines = getattr(mod, 'LEDGER_LINES', None) if mod else None
+    if lines:
+        terminalreporter.write_sep('=', 'parity ledger: HIP path against the float64 oracle fixtures (utils/ledger.REFERENCE_BARS)')
+        for line in lines:
+            terminalreporter.write_line(line)
+
+
 @pytest.fixture(scope='session', autouse=True)
 def shared_tile_choices(tmp_path_factory):
     """ One per-layer tile-choice file for the whole session (GPP_TUNE_CACHE): the dozens of models the GPU tests build time a layer's

@@ -71,7 +71,7 @@ def test_conv_stack_matches_oracle(model50, batch, h, w):
         assert np.sqrt((ef ** 2).mean()) < 0.015 * scale and ef.max() < 0.25, (key, ef.max())
 
 
-@pytest.mark.parametrize('backbone', ['resnet50', pytest.param('resnet101', marks=pytest.mark.slow), 'resnet152'])
+@pytest.mark.parametrize('backbone', ['resnet50', 'resnet101', 'resnet152'])
 def test_predict_on_batch_end_to_end(backbone, oracle_lib):
     batch, h, w = 2, 128, 224
     model = models.load_model('synthetic:7', backbone_name=backbone, dtype='bf16')
