@@ -606,6 +606,16 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import b1_latency
         b1 = b1_latency.measure(model, planes, n=40)
+        b1['plan'] = model.plan_mode
+        if model.plan_mode == 'throughput':
+            # ... and with the plan a caller who times one image per call would load (models.load_model(..., plan='latency'): more layers split
+            # their K loop -- a rule of (layer, plan mode); same bytes at every batch size within the mode, parity bars met: tests/test_latency_plan_gpu.py)
+            from keras_retinanet_3D import models as _models
+            lat_model = _models.load_model('synthetic:1234', backbone_name=args.backbone, dtype=args.dtype, plan='latency')
+            b1_lat = b1_latency.measure(lat_model, planes, n=40)
+            b1_lat['plan'] = 'latency'
+            b1 = dict(b1_lat, default_plan={k: b1[k] for k in ('sync_ms_median', 'sync_ms_p90', 'plan_only_ms_median', 'stages_ms', 'launches', 'floor_ms', 'plan_over_floor', 'plan')})
+            del lat_model
 
     if rank == 0:
         total_images = world * B * args.steps

@@ -234,6 +234,39 @@ def conv_desc(inputs, outputs, weight, bias, KH, KW, C_in, C_out, stride=1, pad=
     return d
 
 
+def default_split(KH, KW, C_in, C_out, pixels_per_image):
+    """ the library's own split-K rule (csrc/conv_igemm.hip split_rule), restated: deep-K layers whose per-image grid is tiny at any batch """
+    tiles = -(-pixels_per_image // 128) * -(-C_out // 128)
+    kdepth = KH * KW * C_in
+    if tiles > 24 or kdepth < 3072:
+        return 1
+    return max(1, min(8, (kdepth + 768) // 1536))
+
+
+def latency_split_config():
+    import os
+    return ';lat={},{},{},{}'.format(os.environ.get('GPP_LAT_MIN_K', '2048'), os.environ.get('GPP_LAT_TARGET', '512'),
+                                     os.environ.get('GPP_LAT_MAX', '8'), os.environ.get('GPP_LAT_STEP_K', '512'))
+
+
+def latency_split(KH, KW, C_in, C_out, pixels_per_image):
+    """ plan='latency' (models.load_model): the split-K factor of a layer as a function of the LAYER ALONE -- kernel size, channels, output
+    pixels per image -- for callers that run one image per call (the reference's own timer, bin/run_network.py:108-111).  At batch 1 a
+    layer of res4 / res5 / the small pyramid levels fields 36 - 140 workgroups for 256 CUs, each pulling its whole K depth of both
+    operands through one CU; splitting K over `split` workgroups per tile fills the chip and shortens every workgroup's chain of
+    dependent tile loads (float32 partial slabs + the deterministic reduce pass of gpp_conv2d_igemm).  Never below the library's own rule,
+    never a function of the batch, the tile or a timing: results are byte-identical at every batch size within the mode. """
+    import os
+    min_k, target = int(os.environ.get('GPP_LAT_MIN_K', '2048')), int(os.environ.get('GPP_LAT_TARGET', '512'))
+    max_split, step_k = int(os.environ.get('GPP_LAT_MAX', '8')), int(os.environ.get('GPP_LAT_STEP_K', '512'))
+    base = default_split(KH, KW, C_in, C_out, pixels_per_image)
+    kdepth = KH * KW * C_in
+    wgs = -(-pixels_per_image // 64) * -(-C_out // 128)          # workgroups of the small tiles a batch-1 launch of this layer runs
+    if kdepth < min_k or wgs >= 256:
+        return base
+    return max(base, min(max_split, -(-target // wgs), max(1, kdepth // step_k)))
+
+
 def run_conv(desc):
     hip.check(hip.lib().gpp_conv2d_igemm(ctypes.byref(desc), hip.stream_ptr()), 'gpp_conv2d_igemm')
 

@@ -44,7 +44,7 @@ def backbone(backbone_name):
 
 
 def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, class_specific_filter=True,
-               orientation_specific_filter=False, dtype=None, on_range_event=None):
+               orientation_specific_filter=False, dtype=None, on_range_event=None, plan=None):
     """ Loads a RetinaNet-3D inference model (reference models/__init__.py:59-88).
 
     `convert` is accepted for signature compatibility: every model this function returns already
@@ -59,6 +59,13 @@ def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, clas
     when one of its activations left the IEEE-half range (beyond +-65504: clamped, counted by the kernels' epilogues) --
         'f32' (default)    the call is run again on a float32 twin of the model and THAT result is returned (the reference's answer, slower)
         'raise'            GppError;      'ignore'   the clamped result is returned (model.x3_range_events() still counts)
+    `plan` (not in the reference; None = the environment's GPP_PLAN, else 'throughput'): how the layers are launched --
+        'throughput'       (default) the plan every batched caller wants: split-K only where a layer's grid is tiny at ANY batch
+        'latency'          for callers that time ONE image per call, as the reference does (bin/run_network.py:108-111): the deep-K layers whose
+                           batch-1 grid leaves most of the 256 CUs idle (res4 / res5 bottlenecks, P4 ... P7, the lateral 1x1s) split their K
+                           loop over more workgroups.  The split is a rule of (layer, plan) -- never of the batch, the tile or a timing -- so a
+                           model gives byte-identical results at every batch size and on every rank WITHIN its plan mode; between the two modes
+                           results differ by float32 summation order only (both inside the parity bars, tests/test_latency_plan_gpu.py)
     """
     import os
     if dtype is None:
@@ -75,7 +82,7 @@ def load_model(filepath, backbone_name='resnet50', convert=False, nms=True, clas
     else:
         w = W.load_weights(filepath)
     model = RetinaNet3D(w, backbone_name=name, dtype=dtype, nms=nms, class_specific_filter=class_specific_filter,
-                        orientation_specific_filter=orientation_specific_filter, on_range_event=on_range_event)
+                        orientation_specific_filter=orientation_specific_filter, on_range_event=on_range_event, plan=plan)
     if convert:
         model.summary()
     return model

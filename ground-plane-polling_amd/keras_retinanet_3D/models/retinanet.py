@@ -196,8 +196,12 @@ class RetinaNet3D(object):
     """ Inference model: ResNet-50/101/152 + FPN + heads + decode + ground-plane polling. """
 
     def __init__(self, weights, backbone_name='resnet50', dtype='f16x3', nms=True, class_specific_filter=True,
-                 orientation_specific_filter=False, name='retinanet-bbox', on_range_event=None):
+                 orientation_specific_filter=False, name='retinanet-bbox', on_range_event=None, plan=None):
         import torch
+        # 'throughput' | 'latency' (models.load_model): which layers split their K loop (layers/conv.latency_split)
+        self.plan_mode = plan or os.environ.get('GPP_PLAN', 'throughput')
+        if self.plan_mode not in ('throughput', 'latency'):
+            raise ValueError("plan must be 'throughput' or 'latency', got {!r}".format(self.plan_mode))
         # dtype='f16x3' only -- what happens when an activation of a call left the IEEE-half range (a finite value beyond +-65504 is
         # clamped when it is split: a plausible wrong answer; the epilogues count such stores, gpp_x3_range_events):
         #   'f32' (default)  the call is run again at dtype='f32' (a float32 twin of the model, built at the first event) and THAT result
@@ -286,8 +290,10 @@ class RetinaNet3D(object):
         kh, kw, cin, cout = shape
         if pad is None:
             pad = (0, 0)
+        # plan='latency': an explicit split-K factor per layer (a function of the layer alone); 0 = the library's own rule
+        split = C.latency_split(kh, kw, cin, cout, sum(f.H * f.W for f in outputs)) if self.plan_mode == 'latency' else 0
         d = C.conv_desc(inputs, outputs, wt, bias, kh, kw, cin, cout, stride=stride, pad=pad, relu=relu,
-                        residuals=residuals, dtype=self.dtype, out_f32=out_f32, out_scale=self.conv_scale.get(name))
+                        residuals=residuals, dtype=self.dtype, out_f32=out_f32, out_scale=self.conv_scale.get(name), split_k=split)
         if self.dtype == 'f16x3':         # this plan's own range-event slot (Plan.range_slot): what its launches count no other plan sees
             d.range_counter = plan.range_slot.data_ptr()
         # split-K partial tiles: the workspace of this op's stream lane is allocated once every op is known (_build)
@@ -675,7 +681,8 @@ class RetinaNet3D(object):
         come and go with it: gpp_version() carries a hash of the kernel sources) and the plan options that change which maps are
         pre-split or fused -- a tile timed on a float32 map may not even exist for the pre-split form of the same layer """
         ver = hip.lib().gpp_version().decode().split('src:')[-1]
-        return 'v2;{};x3split={};fuse={}'.format(ver, os.environ.get('GPP_X3_SPLIT', '2'), os.environ.get('GPP_FUSE_TAIL', '64,128'))
+        return 'v2;{};x3split={};fuse={};plan={}{}'.format(ver, os.environ.get('GPP_X3_SPLIT', '2'), os.environ.get('GPP_FUSE_TAIL', '64,128'), self.plan_mode,
+                                                           C.latency_split_config() if self.plan_mode == 'latency' else '')
 
     def _load_tune_cache(self):
         path = self._tune_cache_path()
@@ -953,7 +960,7 @@ class RetinaNet3D(object):
         if self._twin is None:
             self._twin = RetinaNet3D(self._weights, backbone_name=self.backbone_name, dtype='f32', nms=self.nms,
                                      class_specific_filter=self.class_specific_filter, orientation_specific_filter=self.osf,
-                                     name=self.name + '-f32-twin')
+                                     name=self.name + '-f32-twin', plan=self.plan_mode)
             self._weights = None
         if B is not None:
             self._twin.plan_for(B, H, Wd, n_planes, planes_batched)
