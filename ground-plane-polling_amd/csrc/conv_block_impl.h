@@ -80,9 +80,12 @@ __device__ __forceinline__ void x3_range_if(float (&v)[8], unsigned long long* c
     }
 }
 
-template <int CMID, int TH, int TW>
+// NWAVES wavefronts per workgroup, RING1 stages in the phase-1 ring: C = 128 runs 8 wavefronts on a four-deep ring (144 KB of LDS: one workgroup per
+// CU); C = 64 runs 4 wavefronts on a two-deep ring (72 KB: TWO workgroups per CU, one wavefront of each per SIMD, so that the HBM-bound phases
+// of one workgroup run beside the matrix-bound phase of the other)
+template <int CMID, int TH, int TW, int NWAVES, int RING1>
 struct BlockShape {
-    static constexpr int NW = 8;
+    static constexpr int NW = NWAVES;
     static constexpr int HWD = TW + 2;                       // halo width
     static constexpr int R1 = (TH + 2) * HWD;                // halo pixels: rows of the 2a GEMM
     static constexpr int M2 = TH * TW;                       // output pixels of the tile
@@ -92,13 +95,13 @@ struct BlockShape {
     static constexpr int MB2 = M2 / 16;                      // 16-row blocks of the output tile
     static constexpr int WN2 = WN1, WM2 = WM1;
     static constexpr int MF2 = (MB2 + WM2 - 1) / WM2;
-    static constexpr int WN3 = 4, WM3 = 2;                   // phase 3: 128-column tiles of W3
+    static constexpr int WN3 = 4, WM3 = NW / WN3;            // phase 3: 128-column tiles of W3
     static constexpr int MF3 = (MB2 + WM3 - 1) / WM3;
     static constexpr int PA = R1 / 8;                        // 8-row LDS-DMA pieces of an activation slab
     static constexpr int A_FULL = PA / NW, A_EXTRA = PA - A_FULL * NW;     // pieces every wavefront issues; wavefronts 0 .. A_EXTRA-1 issue one more
     static constexpr int B_IT1 = CMID / 8 / NW;
     static constexpr int A1_BYTES = R1 * kRowBytes, STAGE1 = A1_BYTES + CMID * kRowBytes;
-    static constexpr int S1 = 4;                             // phase-1 ring depth (the a-tile's space is free until the phase ends)
+    static constexpr int S1 = RING1;                         // phase-1 ring depth, a power of two (C = 128: the a-tile's space is free until the phase ends)
     static constexpr int T1_SLAB = R1 * kRowBytes, T1_BYTES = KC * T1_SLAB;
     static constexpr int S2 = 4, STAGE2 = CMID * kRowBytes, B_IT2 = CMID / 8 / NW;
     static constexpr int T2_SLAB = MB2 * 16 * kRowBytes;
@@ -106,6 +109,7 @@ struct BlockShape {
     static constexpr int REGION_B = (S2 * STAGE2 > KC * W3_SLAB) ? S2 * STAGE2 : KC * W3_SLAB;
     static constexpr int LDS = (S1 * STAGE1 > T1_BYTES + REGION_B) ? S1 * STAGE1 : T1_BYTES + REGION_B;
     static_assert(CMID == 64 || CMID == 128, "bottleneck width");
+    static_assert((NW == 4 || NW == 8) && NW % WN1 == 0 && (S1 == 2 || S1 == 4) && CMID % (8 * NW) == 0, "wavefront layout / ring depth");
     static_assert(R1 % (16 * WM1) == 0 && R1 % 8 == 0, "halo rows: whole 16-row blocks per wavefront row, whole 8-row pieces");
     static_assert(M2 % 16 == 0 && HWD % 8 == 0, "tile: whole 16-row blocks; halo width a multiple of 8 (the LDS swizzle key of a tap-shifted row)");
     static_assert(MB2 >= WM2 * MF2 - 1 && MB2 >= WM3 * MF3 - 1, "at most the last wavefront row is one block short");
@@ -117,12 +121,12 @@ struct BlockShape {
 // channels 32 k .. 32 k + 31.  The two wavefronts that will finish those channels in phase 3 copy their 16-byte pieces from the ring into
 // registers there and then (112 - 128 registers per lane by the end of the phase), and the shortcut map is never read a second time: x goes
 // through the fabric once (measured, profiles/r6: 307 -> 157 MB read per res3 block at B = 8).
-template <int DT, int CMID, int TH, int TW, bool IDENT>
-__global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2, const gpp_conv_desc d3,
+template <int DT, int CMID, int TH, int TW, bool IDENT, int NWAVES, int RING1>
+__global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2, const gpp_conv_desc d3,
                                                                       const int tiles_x, const int tiles_y, const int stagger_ticks)
 {
     static_assert(kX3<DT>, "x3 types on pre-split maps");
-    using S = BlockShape<CMID, TH, TW>;
+    using S = BlockShape<CMID, TH, TW, NWAVES, RING1>;
     using xh8 = typename X3Half<DT>::vec;
     using half_t = typename X3Half<DT>::half;
     constexpr bool OSCALE = (DT == GPP_F16X3);
@@ -161,7 +165,11 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
     const int wm3 = wave / S::WN3, wn3 = wave % S::WN3;
     const int nrb3 = __builtin_amdgcn_readfirstlane(min(S::MF3, S::MB2 - wm3 * S::MF3));
     int pix3[S::MF3];                                              // pixel index inside the image, -1 = nothing to store
-    int64_t rbase[S::MF3];
+    // (addresses: uniform 64-bit bases of this image + 32-bit byte offsets per lane -- the launcher checks that a map of the block stays below
+    // 2 GiB -- instead of a 64-bit pointer per row block: those cost the 4-wavefront form, 7 row blocks per lane, its last registers)
+    char* const out_img = (char*)d3.out + ((G3.out_off + (int64_t)b * G3.out_bstride) << 2);
+    const char* const res_img = (const char*)d3.residual + ((G3.res_off + (int64_t)b * G3.res_bstride) << 2);
+    auto map_off = [&](int pixel, int pitch, int n) { return (int)((((unsigned)pixel * (unsigned)pitch + (unsigned)(n & ~31)) << 2) + ((unsigned)(n & 31) << 1)); };
     int ctr_off[IDENT ? S::MF3 : 1];                               // IDENT: where the pixel's own row sits in a ring stage (hi piece; lo: ^ 64)
 #pragma unroll
     for (int i = 0; i < S::MF3; ++i) {
@@ -170,25 +178,24 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
         const int oy = y0 + ty, ox = x0 + tx;
         const bool ok = i < nrb3 && oy < H && ox < W;
         pix3[i] = ok ? oy * W + ox : -1;
-        const int p = ok ? oy * W + ox : 0;                        // (rows past the end: pixel 0 of the image, a valid address that is never stored to)
         if constexpr (IDENT) {
             const int r = (ty + 1) * HWD + tx + 1;                 // its halo row
             ctr_off[i] = (i < nrb3 ? r : 0) * kRowBytes + ((fq ^ (r & 7)) << 4);
         }
-        rbase[i] = G3.res_off + (int64_t)b * G3.res_bstride + (int64_t)p * d3.res_pitch;
     }
     // IDENT: the shortcut rows of the first RT 128-channel output tiles live in registers from phase 1 on; the last tile's are fetched from the
     // map like the general form's (with all four in registers -- 128 per lane -- the compiler spilled 30 of them: the budget is 256 beside
     // the accumulators and fragments of three matrix phases; three quarters of the re-read is what there is room for)
     constexpr int N3T = CMID / 32;                                 // output tiles of an identity block (C_out = 4 C)
-    constexpr int RT = IDENT ? N3T - 1 : 0;
+    constexpr int RT = IDENT ? (CMID == 64 ? N3T : N3T - 1) : 0;
     f32x8 rres[RT > 0 ? RT : 1][S::MF3];                           // [output tile][row block] raw [8 hi][8 lo] bits
     f32x8 rpre[S::MF3];                                            // the prefetched tile of the general form / the last tile of an identity block
     auto prefetch_res = [&](int t) {
         const int n = t * 128 + wn3 * 32 + fq * 8;
 #pragma unroll
         for (int i = 0; i < S::MF3; ++i) {
-            const char* p = x3_addr(d3.residual, rbase[i], n);
+            // (rows past the end: pixel 0 of the image, a valid address whose values are never used)
+            const char* p = res_img + map_off(pix3[i] >= 0 ? pix3[i] : 0, d3.res_pitch, n);
             rpre[i].lo = *(const f32x4*)p;
             rpre[i].hi = *(const f32x4*)(p + 64);
         }
@@ -306,7 +313,6 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr (!IDENT) prefetch_res(0);
 
     constexpr int nk2 = 9 * KC;
     int w2_voff[S::B_IT2];
@@ -441,6 +447,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
                        smem + S::T1_BYTES + kc * S::W3_SLAB + (wave * S::W3_IT + i) * 8 * kRowBytes);
     };
     stage_w3(0);
+    if constexpr (!IDENT) prefetch_res(0);                         // the shortcut rows of output tile 0: in flight under the b-tile's epilogue
     {
         const int n = wn2 * 32 + fq * 8;
         float bias_v[8], scale_v[8];
@@ -537,25 +544,47 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
                 bias_v[e] = d3.bias ? d3.bias[n + e] : 0.0f;
                 scale_v[e] = (OSCALE && d3.out_scale) ? d3.out_scale[n + e] : 1.0f;
             }
-            float outv[NRB][8];
+            // one row block at a time (registers): accumulator -> scale, bias -> + shortcut -> the next tile's shortcut rows of this row block are
+            // requested (general form; before this block's stores go out) -> ReLU, range check, split, store
+            const bool fetch_next = t + 1 < n3_tiles && (!IDENT || t + 1 >= RT);
+            const int n_next = (t + 1) * 128 + wn3 * 32 + fq * 8;
 #pragma unroll
             for (int i = 0; i < NRB; ++i) {
+                float outv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float a = e < 4 ? acc3[i][0][e] : acc3[i][1][e - 4];
-                    if constexpr (OSCALE) outv[i][e] = __builtin_fmaf(a, scale_v[e], bias_v[e]);
-                    else outv[i][e] = a + bias_v[e];
+                    if constexpr (OSCALE) outv[e] = __builtin_fmaf(a, scale_v[e], bias_v[e]);
+                    else outv[e] = a + bias_v[e];
                 }
                 float r[8];
                 if (IDENT && t < RT) x3_unpack<DT>(rres[t < RT ? t : 0][i].lo, rres[t < RT ? t : 0][i].hi, r);
                 else x3_unpack<DT>(rpre[i].lo, rpre[i].hi, r);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) outv[i][e] += r[e];
-            }
-            if (t + 1 < n3_tiles && (!IDENT || t + 1 >= RT)) prefetch_res(t + 1);   // the next tile's shortcut rows: requested before this tile's stores go out
+                for (int e = 0; e < 8; ++e) outv[e] += r[e];
+                const int pixel = pix3[i] >= 0 ? pix3[i] : 0;      // (rows past the end: pixel 0 of the image, a valid address whose values are never used)
+                if (fetch_next) {
+                    const char* p = res_img + map_off(pixel, d3.res_pitch, n_next);
+                    rpre[i].lo = *(const f32x4*)p;
+                    rpre[i].hi = *(const f32x4*)(p + 64);
+                }
+                if (pix3[i] >= 0) {                                // what finish8_pre does for a pre-split output: ReLU, range check, split, two 16-byte stores
+                    if (d3.relu) {
 #pragma unroll
-            for (int i = 0; i < NRB; ++i)
-                if (pix3[i] >= 0) finish8_pre<DT>(d3, outv[i], n, G3.out_off + (int64_t)b * G3.out_bstride + (int64_t)pix3[i] * d3.out_pitch, false, f32x8());
+                        for (int e = 0; e < 8; ++e) outv[e] = fmaxf(outv[e], 0.0f);
+                    }
+                    x3_range<DT>(outv, counter);
+                    xh8 h, l;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        h[e] = (half_t)outv[e];
+                        l[e] = (half_t)(outv[e] - (float)h[e]);
+                    }
+                    char* q = out_img + map_off(pixel, d3.out_pitch, n);
+                    *(xh8*)q = h;
+                    *(xh8*)(q + 64) = l;
+                }
+            }
         }
     };
     if (nrb3 == S::MF3) phase3(IntC<S::MF3>());
@@ -567,12 +596,12 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_x3_kernel(const gpp_c
 #endif
 }
 
-template <int DT, int CMID, int TH, int TW, bool IDENT>
+template <int DT, int CMID, int TH, int TW, bool IDENT, int NWAVES, int RING1>
 int launch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, int stagger_us, hipStream_t st)
 {
-    using S = BlockShape<CMID, TH, TW>;
+    using S = BlockShape<CMID, TH, TW, NWAVES, RING1>;
     static DeviceOnce once;
-    auto kernel = bottleneck_block_x3_kernel<DT, CMID, TH, TW, IDENT>;
+    auto kernel = bottleneck_block_x3_kernel<DT, CMID, TH, TW, IDENT, NWAVES, RING1>;
     int rc = once.configure(kernel, S::LDS);
     if (rc != GPP_OK) return rc;
     const gpp_conv_group& G = d1.groups[0];
@@ -581,6 +610,9 @@ int launch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, int
                   w3_bytes = (int64_t)d3.weight_rows * CMID * 4;
     if (G.in_off < 0 || G.in_bstride < 0 || in_elems * 4 >= (1LL << 31) || w1_bytes >= (1LL << 31) || w2_bytes >= (1LL << 31) || w3_bytes >= (1LL << 31))
         return GPP_ERR_UNSUPPORTED;
+    const gpp_conv_group& G3 = d3.groups[0];
+    const int64_t px = (int64_t)G3.H_out * G3.W_out;
+    if (px * d3.out_pitch * 4 >= (1LL << 31) || px * d3.res_pitch * 4 >= (1LL << 31)) return GPP_ERR_UNSUPPORTED;     // 32-bit byte offsets inside one image
     d1.in_bytes = (int32_t)(in_elems * 4);
     d1.weight_bytes = (int32_t)w1_bytes;
     d2.weight_bytes = (int32_t)w2_bytes;
@@ -588,7 +620,7 @@ int launch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, int
     const int tiles_x = (G.W_out + TW - 1) / TW, tiles_y = (G.H_out + TH - 1) / TH;
     const int64_t grid = (int64_t)d1.batch * tiles_x * tiles_y;
     if (grid >= (1LL << 31)) return GPP_ERR_UNSUPPORTED;
-    kernel<<<dim3((unsigned)grid), dim3(512), S::LDS, st>>>(d1, d2, d3, tiles_x, tiles_y, stagger_us * 100);
+    kernel<<<dim3((unsigned)grid), dim3(64 * NWAVES), S::LDS, st>>>(d1, d2, d3, tiles_x, tiles_y, stagger_us * 100);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? GPP_OK : (int)e;
 }
@@ -610,8 +642,16 @@ int dispatch_block_x3(gpp_conv_desc& d1, gpp_conv_desc& d2, gpp_conv_desc& d3, i
     if (d2.C_in == 128) {
         switch (tile) {
             case 0:
-            case 814: return ident ? launch_block_x3<DT, 128, 8, 14, true>(d1, d2, d3, stagger_us, st)
-                                   : launch_block_x3<DT, 128, 8, 14, false>(d1, d2, d3, stagger_us, st);
+            case 814: return ident ? launch_block_x3<DT, 128, 8, 14, true, 8, 4>(d1, d2, d3, stagger_us, st)
+                                   : launch_block_x3<DT, 128, 8, 14, false, 8, 4>(d1, d2, d3, stagger_us, st);
+            default: return GPP_ERR_BAD_ARG;
+        }
+    }
+    if (d2.C_in == 64) {
+        switch (tile) {
+            case 0:
+            case 814: return ident ? launch_block_x3<DT, 64, 8, 14, true, 4, 2>(d1, d2, d3, stagger_us, st)
+                                   : launch_block_x3<DT, 64, 8, 14, false, 4, 2>(d1, d2, d3, stagger_us, st);
             default: return GPP_ERR_BAD_ARG;
         }
     }

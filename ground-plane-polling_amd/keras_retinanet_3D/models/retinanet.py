@@ -413,10 +413,13 @@ class RetinaNet3D(object):
             fuse_tail = [v for v in fuse_tail if v == 64] if x3_level >= 2 else []
         elif self.esz == 4:
             fuse_tail = []              # float32 operands: no fused tail
-        # widths whose WHOLE blocks (branch2a + 2b + 2c + shortcut) run as one launch (gpp_bottleneck_block; x3 types on pre-split maps, C = 128).
-        # GPP_FUSE_BLOCK="128" turns it on for res3.  Default off: measured at parity with the three launches in isolation and in the step
-        # (profiles/r6/README.md: half the fabric bytes, the same time -- each phase of the fused workgroup is bound by its own latencies)
-        fuse_block = [int(v) for v in os.environ.get('GPP_FUSE_BLOCK', '').split(',') if v.strip()] if (self.dtype in C.X3_TYPES and x3_level >= 2) else []
+        # widths whose IDENTITY blocks (branch2a + 2b + 2c + shortcut) run as one launch (gpp_bottleneck_block; x3 types on pre-split maps): res2 (C = 64:
+        # 4-wavefront workgroups, two per CU; x in once, y out once: 245 -> 212 us per block at B = 8) and res3 (C = 128: 8 wavefronts, one per CU;
+        # at parity with its three launches in isolation, half their fabric bytes).  Same-box A/B of the step (profiles/r6/ab_fuse_block_*.txt):
+        # B = 8: 780 -> 793 images/s (+1.7 %) with both, +0.9 % with res2 alone; B = 4 +1.2 %, B = 2 +0.7 %, batch-1 plan 2.67 -> 2.65 ms.
+        # GPP_FUSE_BLOCK="" for the separate launches (bit-identical either way).  Projection blocks (GPP_FUSE_BLOCK_PROJ=1) measured -0.6 %: off.
+        fuse_block = [int(v) for v in os.environ.get('GPP_FUSE_BLOCK', '64,128').split(',') if v.strip()] if (self.dtype in C.X3_TYPES and x3_level >= 2) else []
+        fuse_block_proj = os.environ.get('GPP_FUSE_BLOCK_PROJ', '0') != '0'      # block 0 of a stage too (its shortcut is the projection launch's map)
 
         def sub(fm, c0, nb):
             return C.FMap(fm.buf, nb, fm.H, fm.W, fm.C, off=fm.off + c0 * fm.bstride, bstride=fm.bstride, pitch=fm.pitch, split=fm.split, half=fm.half)
@@ -458,19 +461,22 @@ class RetinaNet3D(object):
                     if side:
                         sc_ = sub(rec['sc'], c0, nb)
                         self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=1)
-                    rec['block'] = f in fuse_block and f == 128 and rec['sc'] is None and rec['b'] is not None
-                    if rec['block']:
-                        self._block(plan, nm, xs, a_, sub(rec['b'], c0, nb), y_, xs, join=join_halves, lane=ln)
-                    else:
+                    rec['block'] = f in fuse_block and f in (64, 128) and (rec['sc'] is None or fuse_block_proj) and xs.split     # (res2a reads the pooled map, which is float32)
+                    b_or_a = sub(rec['b'], c0, nb) if rec['b'] is not None else a_       # (a stage with fused tails has no branch2b map: the descriptors borrow branch2a's -- neither is written)
+                    if rec['block'] and rec['sc'] is None:
+                        self._block(plan, nm, xs, a_, b_or_a, y_, xs, join=join_halves, lane=ln)
+                    elif not rec['block']:
                         self._conv(plan, 'res{}_branch2a'.format(nm), [xs], [a_], 1, stride=stride, relu=True, lane=ln, join=join_halves)
-                    if join_halves:
-                        lane_open = False
                     if rec['sc'] is not None and not side:
                         sc_ = sub(rec['sc'], c0, nb)
-                        self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=ln)
+                        self._conv(plan, 'res{}_branch1'.format(nm), [xs], [sc_], 1, stride=stride, lane=ln, join=join_halves and rec['block'])
                     elif rec['sc'] is None:
                         sc_ = xs
-                    if rec.get('block'):
+                    if join_halves:
+                        lane_open = False
+                    if rec['block'] and rec['sc'] is not None:           # a projection block: the shortcut map first (side lane or in line), then the whole block
+                        self._block(plan, nm, xs, a_, b_or_a, y_, sc_, stride=stride, join=side, lane=ln)
+                    if rec['block']:
                         pass
                     elif rec['b'] is None:
                         self._tail(plan, nm, a_, y_, sc_, join=side, lane=ln)
@@ -681,7 +687,7 @@ class RetinaNet3D(object):
         come and go with it: gpp_version() carries a hash of the kernel sources) and the plan options that change which maps are
         pre-split or fused -- a tile timed on a float32 map may not even exist for the pre-split form of the same layer """
         ver = hip.lib().gpp_version().decode().split('src:')[-1]
-        return 'v2;{};x3split={};fuse={};plan={}{}'.format(ver, os.environ.get('GPP_X3_SPLIT', '2'), os.environ.get('GPP_FUSE_TAIL', '64,128'), self.plan_mode,
+        return 'v2;{};x3split={};fuse={};plan={}{}'.format(ver, os.environ.get('GPP_X3_SPLIT', '2'), os.environ.get('GPP_FUSE_TAIL', '64,128') + '/' + os.environ.get('GPP_FUSE_BLOCK', '64,128'), self.plan_mode,
                                                            C.latency_split_config() if self.plan_mode == 'latency' else '')
 
     def _load_tune_cache(self):

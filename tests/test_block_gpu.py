@@ -60,11 +60,13 @@ def run_block(d1, d2, d3, tile=0):
 SHAPES = [(2, 25, 31), (1, 7, 5), (3, 9, 40), (1, 51, 167), (2, 8, 14), (1, 17, 29), (1, 1, 1), (2, 16, 28)]
 
 
+@pytest.mark.parametrize('cmid', [128, 64])
 @pytest.mark.parametrize('dtype', ['f16x3', 'bf16x3'])
 @pytest.mark.parametrize('B,H,W', SHAPES)
-def test_identity_block_in_one_launch_gives_the_bytes_of_its_three_layers(B, H, W, dtype):
-    blk = make_block(B, H, W, 128, dtype)
-    y_sep, y_fused = blk['split_map'](H, W, 512), blk['split_map'](H, W, 512)
+def test_identity_block_in_one_launch_gives_the_bytes_of_its_three_layers(B, H, W, dtype, cmid):
+    """ C = 128 (res3: 8 wavefronts, one workgroup per CU) and C = 64 (res2: 4 wavefronts, two workgroups per CU) """
+    blk = make_block(B, H, W, cmid, dtype)
+    y_sep, y_fused = blk['split_map'](H, W, 4 * cmid), blk['split_map'](H, W, 4 * cmid)
     d1, d2, d3 = blk['descs'](y_sep)
     for d in (d1, d2, d3):
         C.run_conv(d)
@@ -84,15 +86,20 @@ def test_identity_block_in_one_launch_gives_the_bytes_of_its_three_layers(B, H, 
     hip.check(run_block(f1, f2, f3), 'gpp_bottleneck_block')
     assert torch.equal(y_fused.buf.view(torch.int32), want.view(torch.int32))
     assert torch.isnan(blk['a'].buf).all() and torch.isnan(blk['b'].buf).all()
+    # ... and the general form (the shortcut read from its map instead of taken from the LDS ring) on the same block: tile code + 1000
+    y_fused.buf.fill_(float('nan'))
+    hip.check(run_block(f1, f2, f3, 1814), 'gpp_bottleneck_block (general form)')
+    assert torch.equal(y_fused.buf.view(torch.int32), want.view(torch.int32))
 
 
 @pytest.mark.parametrize('dtype', ['f16x3', 'bf16x3'])
-@pytest.mark.parametrize('B,H,W,stride,cin', [(2, 25, 31, 2, 256), (1, 101, 67, 2, 256), (2, 13, 20, 1, 64), (1, 9, 9, 2, 512), (1, 30, 44, 1, 256)])
-def test_projection_block_with_a_strided_first_layer(B, H, W, stride, cin, dtype):
-    """ block 0 of a stage: branch2a carries the stride, the shortcut is the map the projection launch wrote """
-    blk = make_block(B, H, W, 128, dtype, stride=stride, cin=cin, seed=7)
+@pytest.mark.parametrize('B,H,W,stride,cin,cmid', [(2, 25, 31, 2, 256, 128), (1, 101, 67, 2, 256, 128), (2, 13, 20, 1, 64, 128), (1, 9, 9, 2, 512, 128),
+                                                  (1, 30, 44, 1, 256, 128), (2, 25, 31, 1, 64, 64), (1, 101, 67, 1, 64, 64), (1, 17, 30, 2, 128, 64)])
+def test_projection_block_with_a_strided_first_layer(B, H, W, stride, cin, cmid, dtype):
+    """ block 0 of a stage: branch2a carries the stride, the shortcut is the map the projection launch wrote (res2a: stride 1, 64 -> 64 -> 256) """
+    blk = make_block(B, H, W, cmid, dtype, stride=stride, cin=cin, seed=7)
     Ho, Wo = blk['Ho'], blk['Wo']
-    y_sep, y_fused = blk['split_map'](Ho, Wo, 512), blk['split_map'](Ho, Wo, 512)
+    y_sep, y_fused = blk['split_map'](Ho, Wo, 4 * cmid), blk['split_map'](Ho, Wo, 4 * cmid)
     for d in blk['descs'](y_sep):
         C.run_conv(d)
     want = y_sep.buf.clone()
@@ -104,13 +111,14 @@ def test_projection_block_with_a_strided_first_layer(B, H, W, stride, cin, dtype
     assert torch.equal(y_fused.buf.view(torch.int32), want.view(torch.int32))
 
 
-def test_block_counts_the_range_events_its_three_layers_count():
+@pytest.mark.parametrize('cmid', [128, 64])
+def test_block_counts_the_range_events_its_three_layers_count(cmid):
     """ GPP_F16X3: activations beyond the half range are clamped AND counted -- once per stored group, as by the separate launches (the
     recomputed halo of a tile is clamped too, and not counted twice) """
     B, H, W = 1, 20, 30
-    blk = make_block(B, H, W, 128, 'f16x3', x_scale=3.0e4)
+    blk = make_block(B, H, W, cmid, 'f16x3', x_scale=3.0e4)
     n = ctypes.c_uint64(0)
-    y_sep, y_fused = blk['split_map'](H, W, 512), blk['split_map'](H, W, 512)
+    y_sep, y_fused = blk['split_map'](H, W, 4 * cmid), blk['split_map'](H, W, 4 * cmid)
     hip.check(hip.lib().gpp_x3_range_events(ctypes.byref(n), 1), 'reset')
     for d in blk['descs'](y_sep):
         C.run_conv(d)

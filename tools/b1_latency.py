@@ -44,7 +44,7 @@ def _stage_ranges(plan):
 
 def _floor_ms(model, plan):
     from keras_retinanet_3D.layers import conv as C
-    from keras_retinanet_3D.models.retinanet import OP_CONV, OP_TAIL
+    from keras_retinanet_3D.models.retinanet import OP_BLOCK, OP_CONV, OP_TAIL
     esz = C.elem_size(model.dtype)
     total, launches = 0.0, 0
     for kind, _, desc, name, flops in plan.ops:
@@ -53,15 +53,18 @@ def _floor_ms(model, plan):
         if kind == OP_TAIL:
             from keras_retinanet_3D.backend import hip
             descs = [ctypes.cast(desc.conv3x3, ctypes.POINTER(hip.ConvDesc)).contents, ctypes.cast(desc.conv1x1, ctypes.POINTER(hip.ConvDesc)).contents]
+        if kind == OP_BLOCK:                 # a whole bottleneck in one launch: neither intermediate map reaches HBM
+            from keras_retinanet_3D.backend import hip
+            descs = [ctypes.cast(p, ctypes.POINTER(hip.ConvDesc)).contents for p in (desc.conv1x1_a, desc.conv3x3_b, desc.conv1x1_c)]
         for j, d in enumerate(descs):
             m_out = sum(d.batch * d.groups[g].H_out * d.groups[g].W_out for g in range(d.n_groups))
             m_in = sum(d.batch * d.groups[g].H_in * d.groups[g].W_in for g in range(d.n_groups))
             k = d.KH * d.KW * d.C_in
             mfma_us = 2.0 * m_out * k * d.C_out / (PEAK[model.dtype] * 1e6)
             byts = d.C_out * k * esz
-            if not (kind == OP_TAIL and j == 1):
-                byts += m_in * d.C_in * esz                     # (the fused tail's intermediate map never reaches HBM)
-            if not (kind == OP_TAIL and j == 0):
+            if not (kind == OP_TAIL and j == 1) and not (kind == OP_BLOCK and j >= 1):
+                byts += m_in * d.C_in * esz                     # (the fused tail's / block's intermediate maps never reach HBM)
+            if not (kind == OP_TAIL and j == 0) and not (kind == OP_BLOCK and j <= 1):
                 byts += m_out * d.C_out * (4 if d.out_f32 else esz) + (m_out * d.C_out * esz if d.residual else 0)
             total += max(mfma_us, byts / (HBM_TBPS * 1e6))
     return (total + launches * LAUNCH_GAP_US) / 1e3, launches
