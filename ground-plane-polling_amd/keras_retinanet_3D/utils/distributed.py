@@ -110,10 +110,11 @@ class ShardedModel(object):
             return pack_outputs(model.outputs(plan))
         import torch
         flat = model.pack_with_range(plan)
-        n = n_local * 100 * PACK_WIDTH
+        det = int(model.outputs(plan)[0].shape[1])                # detections per image (layers.filter_detections.MAX_DETECTIONS)
+        n = n_local * det * PACK_WIDTH
         count = int(flat[n:].cpu().numpy().view(np.uint64)[0])                       # 8 bytes; the stream has reached the end of this rank's plan
         if not model.note_range(plan, count):
-            return flat[:n].view(n_local, 100, PACK_WIDTH)
+            return flat[:n].view(n_local, det, PACK_WIDTH)
         outs = model._range_event([plan.images, plan.P_inv, plan.planes], 'predict_on_batch')
-        host = np.concatenate([np.asarray(o, np.float32).reshape(n_local, 100, -1) for o in outs], axis=2)
+        host = np.concatenate([np.asarray(o, np.float32).reshape(n_local, det, -1) for o in outs], axis=2)
         return torch.as_tensor(np.ascontiguousarray(host)).to(flat.device)

@@ -54,14 +54,15 @@ class FramePipeline(object):
         dev = self.model.device
         self.slots = []
         B = int(frames.shape[0])
+        from ..layers.filter_detections import MAX_DETECTIONS as DET
         for _ in range(self.depth):
             self.slots.append({
                 'd_frames': torch.empty(tuple(frames.shape), dtype=torch.uint8, device=dev),
                 'd_pinv': torch.empty(tuple(P_inv.shape), dtype=torch.float32, device=dev),
                 'd_planes': torch.empty(tuple(planes.shape), dtype=torch.float32, device=dev),
                 # B x 100 x 35 packed detections + the 8 bytes of the f16x3 range-event counter behind them (model.pack_with_range)
-                'd_packed': torch.empty((B * 100 * D.PACK_WIDTH + 2,), dtype=torch.float32, device=dev),
-                'h_packed': torch.empty((B * 100 * D.PACK_WIDTH + 2,), dtype=torch.float32).pin_memory() if (self.pinned or self.inline) else None,
+                'd_packed': torch.empty((B * DET * D.PACK_WIDTH + 2,), dtype=torch.float32, device=dev),
+                'h_packed': torch.empty((B * DET * D.PACK_WIDTH + 2,), dtype=torch.float32).pin_memory() if (self.pinned or self.inline) else None,
                 'B': B,
                 'uploaded': torch.cuda.Event(), 'consumed': torch.cuda.Event(), 'done': torch.cuda.Event(),
                 'downloaded': torch.cuda.Event(),

@@ -14,14 +14,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, void* lds)
 {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, AUX);
 }
 
 // MODE 0: vmcnt wait + barrier per K-step (the conv kernel's loop); MODE 1: no barrier (each wave waits for its own pieces only)
 // WORK: MFMAs per wave and K-step (with 24/64 * WORK ds_read_b128 in front of them), 0 = fills only
-template <int NW, int ROWS_A, int ROWS_B, int STAGES, int MODE, int WORK>
+// SHARED_A (round 6): every workgroup reads the SAME activation rows (an L2-resident operand) instead of rows of its own (first touches from
+// HBM / the Infinity Cache); AUX: cache policy of the activation loads (2 = nt)
+template <int NW, int ROWS_A, int ROWS_B, int STAGES, int MODE, int WORK, bool SHARED_A = false, int AUX = 0>
 __global__ __launch_bounds__(64 * NW) void fill_kernel(const char* A, const char* B, int a_bytes, int b_bytes, int ksteps, float* sink)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(64 * NW) void fill_kernel(const char* A, const char
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
     int a_voff[A_IT], b_voff[B_IT];
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) a_voff[i] = ((blockIdx.x * ROWS_A + (wave * A_IT + i) * 8 + srow)) * pitch + chunk * 16;
+    for (int i = 0; i < A_IT; ++i) a_voff[i] = (((SHARED_A ? 0 : blockIdx.x) * ROWS_A + (wave * A_IT + i) * 8 + srow)) * pitch + chunk * 16;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) b_voff[i] = ((wave * B_IT + i) * 8 + srow) * pitch + chunk * 16;
     auto stage = [&](int buf, int ks) {
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(64 * NW) void fill_kernel(const char* A, const char
         unsigned char* sb = smem + buf * STAGE + ROWS_A * 128 + wave * B_IT * 1024;
         const int so = __builtin_amdgcn_readfirstlane(ks * 128);
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) glds16(ra, a_voff[i], so, sa + i * 1024);
+        for (int i = 0; i < A_IT; ++i) glds16<AUX>(ra, a_voff[i], so, sa + i * 1024);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) glds16(rb, b_voff[i], so, sb + i * 1024);
     };
@@ -80,10 +83,10 @@ __global__ __launch_bounds__(64 * NW) void fill_kernel(const char* A, const char
 
 struct Bufs { char *A, *B; float* sink; size_t a_bytes, b_bytes; };
 
-template <int NW, int ROWS_A, int ROWS_B, int STAGES, int MODE, int WORK>
+template <int NW, int ROWS_A, int ROWS_B, int STAGES, int MODE, int WORK, bool SHARED_A = false, int AUX = 0>
 void run(const Bufs& bf, int wgs, int ksteps, int lds_pad, const char* note)
 {
-    auto k = fill_kernel<NW, ROWS_A, ROWS_B, STAGES, MODE, WORK>;
+    auto k = fill_kernel<NW, ROWS_A, ROWS_B, STAGES, MODE, WORK, SHARED_A, AUX>;
     const int lds = STAGES * (ROWS_A + ROWS_B) * 128 + lds_pad;         // lds_pad forces fewer workgroups per CU
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const size_t need_a = (size_t)wgs * ROWS_A * ksteps * 128, need_b = (size_t)ROWS_B * ksteps * 128;
@@ -147,6 +150,20 @@ int main()
     run<4, 96, 128, 4, 0, 24>(bf, 256, 64, 0, "1 wg/CU 4 stages + work");
     run<4, 96, 128, 5, 0, 24>(bf, 256, 64, 0, "1 wg/CU 5 stages + work");
     run<8, 96 * 2, 128, 3, 0, 24>(bf, 256, 64, 0, "1 wg/CU 8 waves 192+128 3 stages + work");
+    // ---- round 6: where the bytes come from.  The "56 GB/s per CU" of the lines above is a MIX: the activation rows are private to a workgroup (201 MB per
+    // launch: first touches from HBM / the Infinity Cache), the weight rows are L2-hot.  Same loop with every operand L2-resident, with 2 / 4 / 8 / 16 loader
+    // wavefronts, and with the nt policy on the activation loads (MI355X_MICROARCH.md "ldsdma-fill" / "nt-weights" rows)
+    printf("== round 6: operand residency and cache policy, 64 K-steps, 1 workgroup per CU, 96 + 128 rows, fills only\n");
+    run<4, 96, 128, 4, 0, 0, false, 0>(bf, 256, 64, 0, "A private (HBM side), default policy");
+    run<4, 96, 128, 4, 0, 0, false, 2>(bf, 256, 64, 0, "A private (HBM side), nt");
+    run<4, 96, 128, 4, 0, 0, true, 0>(bf, 256, 64, 0, "A shared (L2-resident), default");
+    run<4, 96, 128, 4, 1, 0, true, 0>(bf, 256, 64, 0, "A shared, no barrier");
+    run<2, 96, 128, 4, 1, 0, true, 0>(bf, 256, 64, 0, "A shared, 2 loader wavefronts");
+    run<8, 128, 128, 4, 1, 0, true, 0>(bf, 256, 64, 0, "A shared, 8 loader wavefronts");
+    run<16, 128, 128, 4, 1, 0, true, 0>(bf, 256, 64, 0, "A shared, 16 loader wavefronts");
+    run<4, 96, 128, 4, 0, 0, true, 0>(bf, 32, 64, 0, "A shared, only 32 CUs busy");
+    run<4, 96, 128, 4, 0, 0, false, 0>(bf, 32, 64, 0, "A private, only 32 CUs busy");
+    run<4, 96, 128, 4, 0, 0, false, 2>(bf, 32, 64, 0, "A private nt, only 32 CUs busy");
     // ---- does the K-step time follow the BYTES of a K-step?  (a 3x3 layer re-reads its activation rows once per tap: sharing a staged
     // patch between taps would cut the activation bytes by 2/3 -- worth building only if the loop is bandwidth- and not latency-bound)
     printf("== res4 2b shape (36 K-steps, 364 workgroups, 2 stages, barrier, + work): activation rows per K-step 96 / 64 / 32, weights 128\n");

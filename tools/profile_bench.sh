@@ -9,6 +9,7 @@ dt=${2:-f16x3}
 case $dt in bf16) code=1; gf=431.8;; f16) code=2; gf=431.8;; bf16x3) code=4; gf=431.8;; *) code=5; gf=431.8;; esac
 xin=""; if [ $code -ge 4 ]; then xin=", true"; fi
 fused="0,1"; if [ $code -eq 3 ]; then fused=""; fi; if [ $code -ge 4 ]; then fused="0"; fi      # x3 types: the res2 tails are fused, res3 is not
+blocks=""; if [ $code -ge 4 ]; then blocks="0,1"; fi                                               # x3 types: the identity blocks of res2 / res3 are one launch each (GPP_FUSE_BLOCK)
 mkdir -p $out
 # the per-layer table names the convolution launches by their order in the trace: profiled on ONE stream (the default plan runs res3-res5
 # as two half batches on two streams and P5 / P6 / P7 / P4 on side streams, ~4 % faster on the step; the dominant kernel is not touched by that)
@@ -20,7 +21,7 @@ grep '^{"metric"' $out/bench_under_rocprof.log > $out/bench_under_rocprof.json
 trace=$(find $out/trace -name '*kernel_trace.csv' | head -1)
 stats=$(find $out/trace -name '*kernel_stats.csv' | head -1)
 cp "$stats" $out/kernel_stats.csv
-python3 tools/trace_table.py "$trace" resnet50 "$fused" > $out/per_layer.txt
+python3 tools/trace_table.py "$trace" resnet50 "$fused" "$blocks" > $out/per_layer.txt
 tail -3 $out/per_layer.txt
 python3 - "$trace" "$code" "$dt" "$xin" > $out/dominant_kernel_trace_summary.txt <<'PY'
 import csv, sys

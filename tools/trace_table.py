@@ -9,12 +9,15 @@ sys.path.insert(0, os.path.join(ROOT, 'ground-plane-polling_amd'))
 from keras_retinanet_3D.models import weights as W  # noqa: E402
 
 
-def conv_names(backbone, fused_stages=(0, 1)):
-    """ launch order of models/retinanet.py:_build (fused 2b+2c launches are bottleneck_tail_kernel, not conv_igemm) """
+def conv_names(backbone, fused_stages=(0, 1), block_stages=()):
+    """ launch order of models/retinanet.py:_build (fused 2b+2c launches are bottleneck_tail_kernel, whole identity blocks bottleneck_block_x3_kernel) """
     names = []
     for stage, n in enumerate(W.BLOCKS[backbone]):
         for b in range(n):
             nm = W.block_name(backbone, stage, b)
+            if b > 0 and stage in block_stages:
+                names += ['res%s_2a+2b+2c' % nm]
+                continue
             names += ['res%s_2a' % nm] + (['res%s_br1' % nm] if b == 0 else [])
             names += ['res%s_2b+2c' % nm] if stage in fused_stages else ['res%s_2b' % nm, 'res%s_2c' % nm]
     names += ['C5_reduced', 'P5', 'P6', 'P7', 'C4_reduced', 'P4', 'C3_reduced', 'P3']
@@ -24,6 +27,9 @@ def conv_names(backbone, fused_stages=(0, 1)):
 
 
 def short(k):
+    m = re.search(r'bottleneck_block_x3_kernel<(\d+), (\d+), (\d+), (\d+), (\w+), (\d+)', k)
+    if m:
+        return 'whole block C=%s, %sx%s tiles, %s wavefronts%s' % (m.group(2), m.group(3), m.group(4), m.group(6), ', shortcut from the ring' if m.group(5) in ('true', '1') else '')
     m = re.search(r'bottleneck_tail_kernel<(\d+), (\d+), (\d+)>', k)
     if m:
         return 'fused tail %sx%s' % (m.group(2), m.group(3))
@@ -45,8 +51,9 @@ def short(k):
     return k[:40]
 
 
-def main(path, backbone='resnet50', fused='0,1'):
-    """ fused: stages whose 2b+2c run as one launch ('0,1' = the 16-bit default; '' for the float32-storage types) """
+def main(path, backbone='resnet50', fused='0,1', blocks=''):
+    """ fused: stages whose 2b+2c run as one launch ('0,1' = the 16-bit default; '' for the float32-storage types); blocks: stages whose identity blocks
+    run as one launch (x3 types, GPP_FUSE_BLOCK: '0,1' = res2 + res3) """
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     ours = [r for r in rows if 'at::native' not in r['Kernel_Name'] and 'rocclr' not in r['Kernel_Name']]
@@ -56,7 +63,7 @@ def main(path, backbone='resnet50', fused='0,1'):
     # take the middle of the first 13 (warmup 3 + 10 timed with the profiling command of profiles/README.md)
     steps = [ours[a:b] for a, b in zip(starts, starts[1:] + [len(ours)]) if any('poll_kernel' in r['Kernel_Name'] for r in ours[a:b])]
     step = steps[min(8, len(steps) - 1)]
-    names = conv_names(backbone, tuple(int(v) for v in fused.split(',') if v.strip()))
+    names = conv_names(backbone, tuple(int(v) for v in fused.split(',') if v.strip()), tuple(int(v) for v in blocks.split(',') if v.strip()))
     ci = 0
     t0 = int(step[0]['Start_Timestamp'])
     total = 0.0
@@ -65,7 +72,7 @@ def main(path, backbone='resnet50', fused='0,1'):
         k = r['Kernel_Name']
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         total += d
-        if 'conv_igemm' in k or 'bottleneck_tail' in k or 'conv1x1_ws' in k:
+        if 'conv_igemm' in k or 'bottleneck_tail' in k or 'bottleneck_block' in k or 'conv1x1_ws' in k:
             name = names[ci] if ci < len(names) else '?'
             ci += 1
         elif 'splitk_reduce' in k:
