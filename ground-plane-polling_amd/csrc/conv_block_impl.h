@@ -163,7 +163,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
     }
     // rows of the output tile this lane finishes in phase 3 (and their shortcut rows): wavefront layout WM3 x WN3
     const int wm3 = wave / S::WN3, wn3 = wave % S::WN3;
-    const int nrb3 = __builtin_amdgcn_readfirstlane(min(S::MF3, S::MB2 - wm3 * S::MF3));
+    // a tile that hangs over the bottom edge of the image owns fewer than TH rows of pixels: the 16-row blocks that hold none of them (and the halo
+    // rows below them) are skipped in every phase -- wave-uniform counts of the row blocks a wavefront really works on
+    const int rows_here = min(TH, H - y0);                         // >= 1
+    const int blocks_out = (rows_here * TW + 15) / 16, blocks_halo = ((rows_here + 2) * HWD + 15) / 16;
+    const int nrb3 = __builtin_amdgcn_readfirstlane(max(0, min(min(S::MF3, S::MB2 - wm3 * S::MF3), blocks_out - wm3 * S::MF3)));
     int pix3[S::MF3];                                              // pixel index inside the image, -1 = nothing to store
     // (addresses: uniform 64-bit bases of this image + 32-bit byte offsets per lane -- the launcher checks that a map of the block stays below
     // 2 GiB -- instead of a 64-bit pointer per row block: those cost the 4-wavefront form, 7 row blocks per lane, its last registers)
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
         for (int i = 0; i < S::B_IT1; ++i) glds16(w1_rsrc, w1_voff[i], so, sa + S::A1_BYTES + (wave * S::B_IT1 + i) * 8 * kRowBytes);
     };
     const int wm1 = wave / S::WN1, wn1 = wave % S::WN1;
+    const int nrb1 = __builtin_amdgcn_readfirstlane(max(0, min(S::MF1, blocks_halo - wm1 * S::MF1)));
     int a_rd1[2], b_rd1[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
         }
 #pragma unroll
         for (int i = 0; i < S::MF1; ++i) {
+            if (i >= nrb1) break;
             const xh8 ah = *(const xh8*)(sb + a_rd1[0] + i * 16 * kRowBytes);
             const xh8 al = *(const xh8*)(sb + a_rd1[1] + i * 16 * kRowBytes);
 #pragma unroll
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
                 const unsigned char* sb = smem + (ks & (S::S1 - 1)) * S::STAGE1;
 #pragma unroll
                 for (int i = 0; i < S::MF3; ++i) {
+                    if (i >= nrb3) break;
                     rres[ks >> 2][i].lo = *(const f32x4*)(sb + ctr_off[i]);
                     rres[ks >> 2][i].hi = *(const f32x4*)(sb + (ctr_off[i] ^ 64));
                 }
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
         unsigned char* slab = smem + (n >> 5) * S::T1_SLAB;
 #pragma unroll
         for (int i = 0; i < S::MF1; ++i) {
+            if (i >= nrb1) break;
             const int r = wm1 * (R1 / S::WM1) + i * 16 + frow;
             const int hy = r / HWD, hx = r - hy * HWD;
             const int oy = y0 - 1 + hy, ox = x0 - 1 + hx;
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
     GPP_BSTAMP(2);
     // =============================================================== phase 2: the b-tile = relu(W2 (*) a-tile + b2)
     const int wm2 = wm1, wn2 = wn1;
-    const int nrb2 = __builtin_amdgcn_readfirstlane(min(S::MF2, S::MB2 - wm2 * S::MF2));
+    const int nrb2 = __builtin_amdgcn_readfirstlane(max(0, min(min(S::MF2, S::MB2 - wm2 * S::MF2), blocks_out - wm2 * S::MF2)));
     int t1off[S::MF2][3];                                          // [row block][kw]: byte offset inside a slab of the hi piece of the tap's row, tap row 0 (lo: ^ 64)
 #pragma unroll
     for (int i = 0; i < S::MF2; ++i) {
@@ -388,8 +396,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
 #pragma unroll
     for (int i = 0; i < S::MF2; ++i) { acc2[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    auto phase2 = [&](auto NRB_) {
-        constexpr int NRB = decltype(NRB_)::value;
+    auto phase2 = [&]() {
+        constexpr int NRB = S::MF2;
         for (int cc = 0; cc < KC; ++cc) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
                 }
 #pragma unroll
                 for (int i = 0; i < NRB; ++i) {
+                    if (i >= nrb2) break;
                     const xh8 ah = *(const xh8*)(sa + t1off[i][kw]);
                     const xh8 al = *(const xh8*)(sa + (t1off[i][kw] ^ 64));
 #pragma unroll
@@ -427,8 +436,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
         }
     };
     // (the a-tile is visible to everyone behind the first barrier of the loop)
-    if (nrb2 == S::MF2) phase2(IntC<S::MF2>());
-    else phase2(IntC<(S::MF2 > 1 ? S::MF2 - 1 : 1)>());
+    phase2();
 
     GPP_BSTAMP(3);
     // ---- hand-over 2: everyone is done with the a-tile and the W2 ring; W3 tile 0 streams in while the b-tile is written over the a-tile
@@ -498,8 +506,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
         b_rd3[h] = S::T1_BYTES + (wn3 * 32 + frow) * kRowBytes + sw;
     }
     const int n3_tiles = IDENT ? N3T : d3.C_out / 128;
-    auto phase3 = [&](auto NRB_) {
-        constexpr int NRB = decltype(NRB_)::value;
+    auto phase3 = [&]() {
+        constexpr int NRB = S::MF3;
 #pragma unroll
         for (int t = 0; t < (IDENT ? N3T : n3_tiles); ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -519,6 +527,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
                 }
 #pragma unroll
                 for (int i = 0; i < NRB; ++i) {
+                    if (i >= nrb3) break;
                     const xh8 ah = *(const xh8*)(smem + kc * S::T2_SLAB + a_rd3[0] + i * 16 * kRowBytes);
                     const xh8 al = *(const xh8*)(smem + kc * S::T2_SLAB + a_rd3[1] + i * 16 * kRowBytes);
 #pragma unroll
@@ -550,6 +559,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
             const int n_next = (t + 1) * 128 + wn3 * 32 + fq * 8;
 #pragma unroll
             for (int i = 0; i < NRB; ++i) {
+                if (i >= nrb3) break;
                 float outv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -587,8 +597,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(con
             }
         }
     };
-    if (nrb3 == S::MF3) phase3(IntC<S::MF3>());
-    else phase3(IntC<(S::MF3 > 1 ? S::MF3 - 1 : 1)>());
+    phase3();
     GPP_BSTAMP(5);
 #ifdef GPP_BLOCK_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
