@@ -61,10 +61,12 @@ Lanes g_lanes_of_device[kMaxDevices];
 struct Roctx {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
+    bool sync = false;       // GPP_ROCTX=2: the device is synchronised where a range opens and closes, so that a range's host duration IS its stage's time on the device
     Roctx()
     {
         const char* e = getenv("GPP_ROCTX");
-        if (!e || e[0] != '1') return;
+        if (!e || (e[0] != '1' && e[0] != '2')) return;
+        sync = e[0] == '2';
         for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
             void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (!h) continue;
@@ -116,6 +118,7 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
     int stage_open = 0;
     auto set_stage = [&](int s) {
         if (!roctx.push || s == stage_open) return;
+        if (roctx.sync) (void)hipDeviceSynchronize();
         if (stage_open) (void)roctx.pop();
         if (s) (void)roctx.push(kStageNames[s]);
         stage_open = s;

@@ -412,7 +412,8 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 
 /* Optional stage label of an op, bits 20-23 of `kind`: with GPP_ROCTX=1 in the environment gpp_plan_run opens a roctx range ("gpp:stem", "gpp:backbone",
    "gpp:fpn", "gpp:heads", "gpp:decode", "gpp:polling") around each run of consecutive ops with the same label (rocprofv3 --marker-trace); 0 = none.
-   The marker library is looked up at run time; without the variable nothing is loaded. */
+   The marker library is looked up at run time; without the variable nothing is loaded.  GPP_ROCTX=2 additionally synchronises the device where a range opens and
+   closes: a range's duration in the marker trace is then its stage's time on the device (tools/roctx_stages.sh); a measuring mode, not a production one. */
 #define GPP_OP_STAGE(s) (((s) & 15) << 20)
 #define GPP_STAGE_STEM 1
 #define GPP_STAGE_BACKBONE 2
