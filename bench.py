@@ -51,7 +51,7 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3
 # measured once, not by this script): the clock under matrix load depends on the data, zeros run at the nominal figure above
 PIPE_ON_RANDOM_DATA_TFLOPS = {'bf16': 2033.9, 'f16': 1753.4, 'bf16x3': 2033.9 / 3.0, 'f16x3': 1753.4 / 3.0}
 PIPE_ON_POST_RELU_DATA_TFLOPS = {'bf16': 2134.7, 'f16': 1961.8, 'bf16x3': 2134.7 / 3.0, 'f16x3': 1961.8 / 3.0}      # half of the activation values zero
-PROFILE_ROUNDS = ('r5', 'r4', 'r3')      # the PMC file of the newest round whose library hash matches the running build is quoted
+PROFILE_ROUNDS = ('r6', 'r5', 'r4', 'r3')      # the PMC file of the newest round whose library hash matches the running build is quoted
 # algorithmic bytes of one regression-tower launch at B = 8: M x 512 channels in + out and the packed weights,
 # 2 bytes per element for the 16-bit storage types, 4 for the float32-sized maps of f32 / bf16x3 / f16x3
 ALGORITHMIC_MB = {'bf16': 192.1, 'f16': 192.1, 'f32': 384.2, 'bf16x3': 384.2, 'f16x3': 384.2}
@@ -656,6 +656,9 @@ def main():
                                            'bars (two float32-grade evaluations: the float32 CPU oracle itself is 1.15e-3 m from the float64 one, '
                                            'utils/ledger.py)'),
                        'parity_bars_met': bars_met,
+                       # dtype='f16x3': range events every plan of this model counted over the WHOLE run (timed loop included: run_plan callers do not fetch
+                       # through model.fetch, which would have reacted) -- an activation beyond +-65504 would have been clamped; must be 0
+                       'f16x3_range_events_in_run': model.x3_range_events() if args.dtype == 'f16x3' else None,
                        'resident_batches_rotated': RESIDENT_BATCHES,
                        'side_stream_launches': dict(getattr(plan, 'side_lanes', {}), decode=bool(getattr(plan, 'decode_overlap', False))),
                        'multi_gpu_diagnosis': per_rank,
@@ -715,6 +718,8 @@ def main():
                 raise SystemExit('decode / polling of the GPU head tensors differ from the oracle replay')
         print(json.dumps(rec))
         headline = args.dtype == 'f16x3' and args.backbone == 'resnet50' and args.planes == '1k' and B == 8
+        if rec['config'].get('f16x3_range_events_in_run'):
+            raise SystemExit('dtype f16x3: {} range events during the run: the timed results were clamped'.format(rec['config']['f16x3_range_events_in_run']))
         if bars_met is False and headline:           # (other configurations report parity_bars_met and carry on)
             raise SystemExit('the headline type {} misses a reference-precision bar: {}'.format(args.dtype, parity))
     for e in events:

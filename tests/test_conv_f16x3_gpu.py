@@ -215,7 +215,12 @@ def test_the_96_column_tile_on_the_logits_shape(dtype, cout):
         ins.append(fm)
         off += h * wd
     tiles, count = (ctypes.c_int * 32)(), ctypes.c_int(0)
-    probe = C.conv_desc(ins, ins, w, b, 3, 3, cin, cout, pad=(1, 1), dtype=dtype, out_f32=True, out_scale=scale)
+    o_probe = torch.empty((B, total, cout), dtype=torch.float32, device=dev)
+    outs_probe, off = [], 0
+    for h, wd in shapes:
+        outs_probe.append(C.FMap(o_probe, B, h, wd, cout, off=off * cout, bstride=total * cout))
+        off += h * wd
+    probe = C.conv_desc(ins, outs_probe, w, b, 3, 3, cin, cout, pad=(1, 1), dtype=dtype, out_f32=True, out_scale=scale)      # (the library validates what it lists tiles for)
     hip.check(hip.lib().gpp_conv2d_tile_candidates(ctypes.byref(probe), tiles, 32, ctypes.byref(count)), 'gpp_conv2d_tile_candidates')
     assert 1192096 in list(tiles[:count.value])                      # offered to the autotuner where it cuts the N padding
     results = []
