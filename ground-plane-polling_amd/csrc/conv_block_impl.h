@@ -8,10 +8,11 @@
 // b out, b in, x in again as the shortcut, y out) for 552 / 280 MB of x-in / y-out; the two intermediate maps are what this kernel
 // never writes.  bottleneck_tail_x3_kernel (conv_igemm_impl.h) already keeps `b` in LDS; this one keeps `a` there too.
 //
-// One workgroup (8 wavefronts, one per CU: the LDS footprint is ~144 KB) computes a TH x TW tile of output pixels of one image:
+// One workgroup -- C = 128: 8 wavefronts, 144 KB of LDS, one per CU; C = 64: 4 wavefronts, 72 KB, TWO per CU, so that the HBM-bound phases of one
+// run beside the matrix-bound phase of the other -- computes a TH x TW tile of output pixels of one image:
 //   phase 1  a-tile = relu(W1 * x + b1) on the tile PLUS its one-pixel halo, (TH+2) x (TW+2) = R1 rows of a GEMM with K = C_in:
-//            x rows and W1 rows stream through a four-deep LDS ring (three K-steps of LDS-DMA in flight: the x rows are first touches
-//            from HBM); the result goes accumulators -> (scale, bias, ReLU, range check, split) -> LDS as the pre-split rows the
+//            x rows and W1 rows stream through an LDS ring (C = 128: four deep, three K-steps of LDS-DMA in flight -- the x rows are first
+//            touches from HBM; C = 64: two deep); the result goes accumulators -> (scale, bias, ReLU, range check, split) -> LDS as the pre-split rows the
 //            unfused layer would have stored; halo pixels outside the image are the 3x3 layer's zero padding: zero rows.
 //            The halo is recomputed by the neighbouring tiles (R1 / (TH TW) = 1.43 x the 2a work, which is 1/4.5 of the block's).
 //   phase 2  b-tile = relu(W2 (*) a-tile + b2): implicit GEMM with the A operand read STRAIGHT from the a-tile in LDS (tap (kh, kw) of
@@ -23,6 +24,13 @@
 // hi*wlo, hi*whi, lo*whi per K-step, fma(acc, out_scale, bias), shortcut added as float32(hi) + float32(lo), ReLU, clamp, split -- so the
 // result is BIT-IDENTICAL to gpp_conv2d_igemm x 3 (tests/test_block_gpu.py) and the kernel is a pure scheduling choice of the plan.
 // Range events (GPP_F16X3) are counted once per stored group, for the pixels the tile owns (not for the recomputed halo).
+//
+// Measured (profiles/r6, B = 8, same box): res2 identity block 245 us (branch2a + fused tail) -> 205 us, fabric bytes 966 -> ~600 MB; res3
+// identity block 185 us (three launches) -> 180 us, read bytes 307 (general form) -> 195 MB; the step +1.7 %.  What holds the C = 128 form at
+// parity: one workgroup per CU runs its three phases one after the other -- 17 us of x in at the chip's HBM rate, 20 us of matrix work
+// that touches no HBM, 20 us of y out -- and all workgroups of a round do so in lockstep (block_stamps_*.txt); starting half of them late
+// (tile + 10000 k), the W2 fragments straight from L2 into registers (no barriers in phase 2: 35 us instead of 20) and one barrier per
+// two K-steps were measured and changed nothing or lost.  C = 256 (res4) does not fit: its a-tile alone is 160 KB.
 #ifndef GPP_CONV_BLOCK_IMPL_H_
 #define GPP_CONV_BLOCK_IMPL_H_
 
@@ -119,8 +127,8 @@ struct BlockShape {
 // IDENT: an identity block -- the shortcut IS the block's input (same map, stride 1, C_in = 4 C).  Its rows pass through the LDS ring in
 // phase 1 anyway: K-step k of branch2a stages channels 32 k .. 32 k + 31 of every halo pixel, which are the shortcut values of output
 // channels 32 k .. 32 k + 31.  The two wavefronts that will finish those channels in phase 3 copy their 16-byte pieces from the ring into
-// registers there and then (112 - 128 registers per lane by the end of the phase), and the shortcut map is never read a second time: x goes
-// through the fabric once (measured, profiles/r6: 307 -> 157 MB read per res3 block at B = 8).
+// registers there and then, and those channels of the shortcut map are never read a second time (C = 64: all 256 channels, 112 registers per
+// lane; C = 128: 384 of 512 -- the fourth output tile's rows are fetched like the general form's: with all of them the compiler spilled).
 template <int DT, int CMID, int TH, int TW, bool IDENT, int NWAVES, int RING1>
 __global__ __launch_bounds__(64 * NWAVES, 2) void bottleneck_block_x3_kernel(const gpp_conv_desc d1, const gpp_conv_desc d2, const gpp_conv_desc d3,
                                                                       const int tiles_x, const int tiles_y, const int stagger_ticks)

@@ -225,11 +225,14 @@ int gpp_bottleneck_tail(const gpp_conv_desc* conv3x3, const gpp_conv_desc* conv1
 
 /* A WHOLE bottleneck of the same graph in one launch (GPP_F16X3 / GPP_BF16X3 on pre-split maps): "branch2a" (1x1, C_in -> C, stride 1 or 2, + bias
    + ReLU), "branch2b" (3x3, C -> C, stride 1, pad 1, + bias + ReLU) and "branch2c" (1x1, C -> multiple of 128, + bias + shortcut + ReLU), C = 64 or
-   128; both intermediate maps stay in LDS (a workgroup computes a tile of output pixels and recomputes branch2a on its one-pixel halo).
+   128; both intermediate maps stay in LDS (a workgroup computes a tile of 8 x 14 output pixels and recomputes branch2a on its one-pixel halo).
    conv1x1_a->out and conv3x3_b->out are not written.  Results are bit-identical to the three gpp_conv2d_igemm launches (same K order and
-   the same epilogue arithmetic per output element).  The shortcut is conv1x1_c->residual: the block's input map (identity blocks) or the map a
-   projection launch wrote.  tile: 0 = the library's choice, TH * 100 + TW = a tile of TH x TW output pixels (gpp_bottleneck_block_tiles lists what a
-   width accepts).  Other shapes / types: GPP_ERR_UNSUPPORTED. */
+   the same epilogue arithmetic per output element; range events counted once per stored group, as the three launches count them).  The
+   shortcut is conv1x1_c->residual: a map a projection launch wrote, or the block's own input map -- an identity block (same pointer, offsets and
+   pitches as conv1x1_a's input, stride 1, C_in = 4 C), whose shortcut rows are then taken from the LDS ring they pass through anyway and the map is
+   read once (C = 64) / 1.25 times (C = 128) instead of twice.  tile: 0 = the library's choice (814 = 8 x 14 pixels, the only tile built);
+   + 1000 forces the general form (the shortcut read from its map) on an identity block; + 10000 k: the odd tile rows start k microseconds late
+   (an experiment).  Every map of the block must stay below 2 GiB per image.  Other shapes / types: GPP_ERR_UNSUPPORTED. */
 int gpp_bottleneck_block(const gpp_conv_desc* conv1x1_a, const gpp_conv_desc* conv3x3_b, const gpp_conv_desc* conv1x1_c, int tile, void* stream);
 
 /* GPP_F16X3 range ledger.  The half type ends at +-65504: an epilogue that stores an activation outside it (a finite value it has to
