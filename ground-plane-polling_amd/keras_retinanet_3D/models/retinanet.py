@@ -346,8 +346,11 @@ class RetinaNet3D(object):
         # split-K partial tiles of the deep-K layers with a tiny per-image grid (res5 branch2b, P5..P7); one workspace per
         # stream lane (concurrent launches must not share partial tiles), sized from the descriptors at the end of _build
         head_lanes = os.environ.get('GPP_HEAD_LANES', '0') != '0'
-        # res3 .. res5 run as two half batches, the second half on a side stream beside the first (GPP_HALF_LANES="" for whole batches)
-        half_stages = set(int(v) for v in os.environ.get('GPP_HALF_LANES', '1,2,3').split(',') if v.strip()) if B >= 2 else set()
+        # res2 .. res5 run as two half batches, the second half on a side stream beside the first (GPP_HALF_LANES="" for whole batches).  res2 joined the
+        # list in round 6: with its identity blocks as one two-per-CU launch each (gpp_bottleneck_block) two half-batch chains overlap the HBM-bound phases
+        # of one with the matrix phase of the other -- same box, alternating: B = 8 812.8 -> 818.7 images/s (+0.7 %), B = 4 +1.1 %, B = 2 +1.1 %
+        # (profiles/r6/ab_half_lanes_with_blocks.txt); before (rounds 4 - 5, separate launches) it lost
+        half_stages = set(int(v) for v in os.environ.get('GPP_HALF_LANES', '0,1,2,3').split(',') if v.strip()) if B >= 2 else set()
         br1_lane = os.environ.get('GPP_BR1_LANE', '1') != '0'         # measured +0.4 % on the f16x3 step (same box, alternating)
         plan.conv_descs, plan.ws_need = [], {}
         # dtype='f16x3': the 8-byte counter every launch of THIS plan adds its range events to (gpp_conv_desc.range_counter, gpp_stem_desc.range_counter),
@@ -441,7 +444,7 @@ class RetinaNet3D(object):
                 blocks.append(rec)
                 x = rec['y']
             chunk = max(1, min(B, int(env_chunks.split(',')[stage]))) if env_chunks else B
-            # GPP_HALF_LANES (default "1,2,3" = res3, res4, res5): the stage as two half batches, the second half on a side stream beside
+            # GPP_HALF_LANES (default "0,1,2,3" = res2 .. res5): the stage as two half batches, the second half on a side stream beside
             # the first.  A launch of these stages fills the 256 CUs 0.7 - 1.4 times and is bound by tile fills and first-touch latency;
             # two independent chains in flight overlap one's prologue / epilogue / barrier waits with the other's main loop (f16x3 step,
             # same box, alternating: 775 -> 793 images/s).  An image's result does not depend on its batch (section 4.4): same bytes.

@@ -182,8 +182,8 @@ def test_decode_overlap_does_not_change_results(monkeypatch):
 
 @pytest.mark.parametrize('dtype', ['f16x3', 'bf16'])
 def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
-    """ default plan: res3 .. res5 as two half batches (1 + 2 images here) on two streams; the projection shortcut of res2's first block
-    on a side stream beside branch2a / 2b, P5 and the
+    """ default plan: res2 .. res5 as two half batches (1 + 2 images here) on two streams (a stage that is NOT split puts the projection shortcut of its
+    first block on a side stream beside branch2a / 2b: GPP_HALF_LANES=1,2,3 in the plan-variant test below), P5 and the
     P6 -> ReLU -> P7 chain beside C4_reduced, P4 (behind P5) beside C3_reduced / P3.  GPP_BR1_LANE=0 GPP_FPN_LANES=0: everything on one stream.  Disjoint outputs,
     explicit joins: identical bytes, head tensors and pyramid included, also on repeated runs. """
     planes = synthetic.load_plane_database('100').astype(np.float32)
@@ -203,10 +203,9 @@ def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
         return outs, plan
 
     lanes, plan = run(4)
-    assert plan.side_lanes == {'fpn': True, 'branch1': True, 'p4': True, 'half_batch_stages': [1, 2, 3], 'cls_tower': False}
+    assert plan.side_lanes == {'fpn': True, 'branch1': True, 'p4': True, 'half_batch_stages': [0, 1, 2, 3], 'cls_tower': False}
     names = [op[3] for op in plan.ops]
-    assert names.index('res2a_branch1') < names.index('res2a_branch2a')          # forked before the chain it runs beside
-    assert names.count('res4b_branch2b') == 2                                    # one launch per half batch
+    assert names.count('res4b_branch2b') == 2 and names.count('res2a_branch2a') == 2      # one launch per half batch (res2 too since round 6)
     monkeypatch.setenv('GPP_BR1_LANE', '0')
     monkeypatch.setenv('GPP_FPN_LANES', '0')
     monkeypatch.setenv('GPP_HALF_LANES', '')
@@ -221,12 +220,13 @@ def test_side_stream_lanes_do_not_change_results(dtype, monkeypatch):
 PLAN_OPTIONS = [{}, {'GPP_HALF_LANES': '1,2'}, {'GPP_HALF_LANES': '1'}, {'GPP_HALF_LANES': '2'}, {'GPP_HALF_LANES': '0,1,2,3'}, {'GPP_HALF_LANES': '0,2'},
                 {'GPP_HALF_LANES': ''}, {'GPP_BR1_LANE': '0'}, {'GPP_FPN_LANES': '0'}, {'GPP_P4_LANE': '0'}, {'GPP_HEAD_LANES': '1'},
                 {'GPP_DECODE_OVERLAP': '0'}, {'GPP_STAGE_CHUNKS': '4,8,8,8'}, {'GPP_STAGE_CHUNKS': '2,4,8,8', 'GPP_HALF_LANES': '2,3'},
-                {'GPP_HALF_LANES': '3', 'GPP_FPN_LANES': '0', 'GPP_BR1_LANE': '0'}, {'GPP_CLS_LANE': '1'}, {'GPP_CLS_LANE': '1', 'GPP_HALF_LANES': ''}]
+                {'GPP_HALF_LANES': '3', 'GPP_FPN_LANES': '0', 'GPP_BR1_LANE': '0'}, {'GPP_CLS_LANE': '1'}, {'GPP_CLS_LANE': '1', 'GPP_HALF_LANES': ''},
+                {'GPP_HALF_LANES': '1,2,3'}, {'GPP_FUSE_BLOCK': ''}, {'GPP_FUSE_BLOCK': '64,128', 'GPP_FUSE_BLOCK_PROJ': '1'}]      # (round 6: the old default; no fused blocks; projection blocks fused too)
 
 
 # the default GPU run keeps the settings that changed a plan's shape in a way of its own (the default, the split / unsplit pattern of the round-4 race,
 # towers on side streams, chunked stages, no half batches); the rest of the matrix runs under --run-slow (tools/collect_r5.sh)
-PLAN_OPTIONS_DEFAULT_RUN = (0, 1, 10, 15)
+PLAN_OPTIONS_DEFAULT_RUN = (0, 1, 10, 15, 17, 18)
 
 
 @pytest.mark.parametrize('options', [o if i in PLAN_OPTIONS_DEFAULT_RUN else pytest.param(o, marks=pytest.mark.slow) for i, o in enumerate(PLAN_OPTIONS)],
@@ -246,7 +246,7 @@ def test_every_plan_variant_orders_its_streams_and_gives_the_same_bytes(options,
     inputs = [x, P, np.tile(planes[None], (4, 1, 1))]
 
     def run(env):
-        for k in ('GPP_HALF_LANES', 'GPP_BR1_LANE', 'GPP_FPN_LANES', 'GPP_P4_LANE', 'GPP_HEAD_LANES', 'GPP_DECODE_OVERLAP', 'GPP_STAGE_CHUNKS', 'GPP_CLS_LANE'):
+        for k in ('GPP_HALF_LANES', 'GPP_BR1_LANE', 'GPP_FPN_LANES', 'GPP_P4_LANE', 'GPP_HEAD_LANES', 'GPP_DECODE_OVERLAP', 'GPP_STAGE_CHUNKS', 'GPP_CLS_LANE', 'GPP_FUSE_BLOCK', 'GPP_FUSE_BLOCK_PROJ'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
