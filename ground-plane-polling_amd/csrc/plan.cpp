@@ -169,7 +169,10 @@ extern "C" int gpp_plan_run(const gpp_plan_op* ops, int n_ops, void* stream, voi
         }
         case GPP_OP_STEM_POOL: {
             const gpp_stem_desc* d = (const gpp_stem_desc*)op.desc;
-            rc = gpp_stem_pool_fused_mfma(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
+            if (d->dtype == GPP_F16X3 || d->dtype == GPP_BF16X3)
+                rc = gpp_stem_pool_fused_x3(d->in, d->weight, d->bias, (float*)d->out, d->B, d->H, d->W, d->range_counter, stream);
+            else
+                rc = gpp_stem_pool_fused_mfma(d->in, d->weight, d->bias, d->out, d->dtype, d->B, d->H, d->W, stream);
             break;
         }
         case GPP_OP_MAXPOOL: {

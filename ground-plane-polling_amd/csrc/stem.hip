@@ -529,6 +529,210 @@ __global__ __launch_bounds__(64 * FP_ROWS, 8 / FP_ROWS) void stem_pool_mfma_kern
     }
 }
 
+// ---- x3 stem fused with pool1 (round 6) ------------------------------------------------------------
+// conv1 + bn_conv1 + ReLU + pool1 of the float32-storage x3 types in one launch: stem_mfma_x3_kernel's matrix work on the steps
+// of stem_pool_mfma_kernel (a persistent workgroup marches down a strip of 64 conv columns, one conv row per wavefront, the last row of a
+// step carried to the next).  A ring of float32 conv rows does not fit beside 58 KB of hi / lo weights (9 x 16 KB); what the ring holds
+// here is each conv row AFTER the horizontal half of the pool -- max over conv columns 2j .. 2j + 2, taken in registers with row shifts
+// of the accumulator lanes (a lane holds one pixel of a 16-pixel fragment; pixel 14's third column comes from the next fragment) --
+// i.e. 31 pooled columns x 64 channels x 4 bytes = 7.75 KB per row.  The vertical half reads three ring rows per pooled pixel.
+// max is exact and has no order, so the result is bit-identical to gpp_stem_conv7x7_bn_relu_x3 + gpp_maxpool3x3s2_same(GPP_F32), and a
+// conv value beyond the half range is counted exactly as there: once per (pixel, 32-channel group) of the conv map, by the workgroup
+// that OWNS the pixel (strips overlap by two conv columns, a range's first carried row is computed twice).
+// The (B, Ho, Wo, 64) float32 conv map -- 274 MB at B = 8, 402 x 1333, written and read back -- never exists.
+// FP_ROWS = conv rows per step = wavefronts: 6 (142 KB of LDS) or 4 (119 KB); one workgroup per CU either way.
+constexpr int XP_ROW_BYTES = 32 * 64 * 4;         // one half-pooled conv row of a strip: 32 (31 used) columns x 64 channels float32
+constexpr int xp_lds(int rows) { return 2 * FP_W_BYTES + 2 * (rows * 2 + 5) * MP_PITCH * 2 + (rows + 1) * XP_ROW_BYTES + 128 * 4; }
+
+// lane l of a row of 16 receives the value of lane l + n (row_shl) / l - n (row_shr); lanes whose source is outside the row keep `old`
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+template <int FP_ROWS>
+__global__ __launch_bounds__(64 * FP_ROWS) void stem_pool_mfma_x3_kernel(const float* __restrict__ in, const _Float16* __restrict__ w,
+                                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                                      int B, int H, int W, int Ho, int Wo, int Hp, int Wp, int pt, int pl,
+                                                                      unsigned long long* range_events)
+{
+    constexpr int PROWS = FP_ROWS * 2 + 5, RING = FP_ROWS + 1, NT = 64 * FP_ROWS, PR = FP_ROWS / 2;
+    constexpr int W_HALFS = 64 * MW_PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+    _Float16* s_wh = (_Float16*)qsm;
+    _Float16* s_wl = s_wh + W_HALFS;
+    _Float16* s_ph = s_wl + W_HALFS;
+    _Float16* s_pl = s_ph + PROWS * MP_PITCH;
+    unsigned char* s_c = (unsigned char*)(s_pl + PROWS * MP_PITCH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 2 * W_HALFS / 8; e += NT) ((uint4*)s_wh)[e] = ((const uint4*)w)[e];
+    // out_scale and bias of the 64 channels: read from LDS in the epilogue (held in registers across the matrix loop they cost 32 VGPRs -- spills at 6 wavefronts)
+    float* s_sb = (float*)(s_c + RING * XP_ROW_BYTES);
+    if (tid < 64) { s_sb[tid] = ((const float*)(w + 2 * W_HALFS))[tid]; s_sb[64 + tid] = bias[tid]; }
+    const int n_strips = (Wp + FP_PCOLS - 1) / FP_PCOLS, n_blocks = (Hp + PR - 1) / PR;
+    const int64_t total = (int64_t)B * n_strips * n_blocks;
+    const int lo = (int)(total * blockIdx.x / gridDim.x), hi = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr int PATCH_PAIRS = PROWS * (MP_PITCH / 2);
+    constexpr int PATCH_IT = (PATCH_PAIRS + NT - 1) / NT;
+    float patch[PATCH_IT][2];
+    // step idx = ((b * n_strips) + s) * n_blocks + t; a pre-step of step (b, s, t) is row block t - 1, last wavefront only
+    auto load_patch = [&](int idx, bool pre) {
+        const int t = idx % n_blocks, bs = idx / n_blocks;
+        const int sidx = bs % n_strips, b = bs / n_strips;
+        const int tt = pre ? t - 1 : t;
+        const int iy0 = (FP_ROWS * tt - pt + 1) * 2 - 3, ix0 = (2 * FP_PCOLS * sidx - pl) * 2 - 3;
+        const float* img = in + (size_t)b * H * W * 3;
+#pragma unroll
+        for (int it = 0; it < PATCH_IT; ++it) {
+            const int e = tid + it * NT;
+            const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
+            const int iy = iy0 + pr;
+            const int x0 = ix0 * 3 + c2;
+            float v0 = 0.0f, v1 = 0.0f;
+            if (e < PATCH_PAIRS && (unsigned)iy < (unsigned)H) {
+                const float* rowp = img + (size_t)iy * W * 3;
+                if (x0 >= 0 && x0 < W * 3) v0 = rowp[x0];
+                if (x0 + 1 >= 0 && x0 + 1 < W * 3) v1 = rowp[x0 + 1];
+            }
+            patch[it][0] = v0;
+            patch[it][1] = v1;
+        }
+    };
+    // the carried row of the first step of a range comes from nobody: compute it, unless it is the padding row above the map
+    auto needs_pre = [&](int idx, bool first) { return (idx % n_blocks) == 0 ? (pt == 0) : first; };
+    int idx = lo;
+    bool pre = lo < hi && needs_pre(lo, true);
+    if (lo < hi) load_patch(idx, pre);
+    while (idx < hi) {
+        const int t = idx % n_blocks, bs = idx / n_blocks;
+        const int sidx = bs % n_strips, b = bs / n_strips;
+        const int tt = pre ? t - 1 : t;
+        __syncthreads();                                     // the previous step's readers are done with the patch and the ring
+#pragma unroll
+        for (int it = 0; it < PATCH_IT; ++it) {
+            const int e = tid + it * NT;
+            const int pr = e / (MP_PITCH / 2), c2 = (e - pr * (MP_PITCH / 2)) * 2;
+            if (e < PATCH_PAIRS) {
+                const _Float16 h0 = (_Float16)patch[it][0], h1 = (_Float16)patch[it][1];
+                *(f16x2*)(s_ph + pr * MP_PITCH + c2) = (f16x2){h0, h1};
+                *(f16x2*)(s_pl + pr * MP_PITCH + c2) = (f16x2){(_Float16)(patch[it][0] - (float)h0), (_Float16)(patch[it][1] - (float)h1)};
+            }
+        }
+        __syncthreads();
+        const int nidx = pre ? idx : idx + 1;
+        const bool npre = pre ? false : (nidx < hi && needs_pre(nidx, false));
+        if (nidx < hi) load_patch(nidx, npre);
+        if (!pre || wave == FP_ROWS - 1) {
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) {
+                f16x8 wh[4], wl[4], xh[4], xl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wh[j] = *(const f16x8*)(s_wh + (j * 16 + frow) * MW_PITCH + kh * 32 + fq * 8);
+                    wl[j] = *(const f16x8*)(s_wl + (j * 16 + frow) * MW_PITCH + kh * 32 + fq * 8);
+                }
+                const int poff = (wave * 2 + kh) * MP_PITCH + fq * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f16x2* sh = (const f16x2*)(s_ph + poff + (i * 16 + frow) * 6);
+                    const f16x2* sl = (const f16x2*)(s_pl + poff + (i * 16 + frow) * 6);
+                    const f16x2 a0 = sh[0], a1 = sh[1], a2 = sh[2], a3 = sh[3];
+                    const f16x2 c0 = sl[0], c1 = sl[1], c2 = sl[2], c3 = sl[3];
+                    xh[i] = (f16x8){a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+                    xl[i] = (f16x8){c0[0], c0[1], c1[0], c1[1], c2[0], c2[1], c3[0], c3[1]};
+                }
+                // the product order of stem_mfma_x3_kernel (the accumulation order is part of the result)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+            }
+            // conv row FP_ROWS tt - pt + 1 + wave: the stored values of the unfused stem, in place of the accumulators
+            const int crow_idx = FP_ROWS * tt - pt + 1 + wave;
+            const int c0 = 2 * FP_PCOLS * sidx - pl;
+            const bool count_row = (unsigned)crow_idx < (unsigned)Ho && (!pre || t == 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cr = i * 16 + frow;
+                const bool col_ok = (unsigned)(c0 + cr) < (unsigned)Wo;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    bool outside = false;
+                    const f32x4 sc0 = *(const f32x4*)(s_sb + jj * 32 + fq * 8), sc1 = *(const f32x4*)(s_sb + jj * 32 + fq * 8 + 4);
+                    const f32x4 bi0 = *(const f32x4*)(s_sb + 64 + jj * 32 + fq * 8), bi1 = *(const f32x4*)(s_sb + 64 + jj * 32 + fq * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v0 = fmaxf(acc[i][2 * jj][e] * sc0[e] + bi0[e], 0.0f);
+                        const float v1 = fmaxf(acc[i][2 * jj + 1][e] * sc1[e] + bi1[e], 0.0f);
+                        outside |= !(v0 <= 65504.0f) | !(v1 <= 65504.0f);
+                        acc[i][2 * jj][e] = col_ok ? v0 : -INFINITY;           // a column outside the conv map never wins
+                        acc[i][2 * jj + 1][e] = col_ok ? v1 : -INFINITY;
+                    }
+                    if (__builtin_expect(outside && count_row && col_ok && cr < 2 * FP_PCOLS, 0)) atomicAdd(range_events, 1ull);
+                }
+            }
+            // horizontal half of the pool: pooled column q = conv columns 2q, 2q + 1, 2q + 2 of the strip -> the even lanes of a fragment
+            float* hrow = (float*)(s_c + ((FP_ROWS * tt + 1 + wave + RING) % RING) * XP_ROW_BYTES);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = i * 8 + (frow >> 1);
+                const bool producer = !(frow & 1) && q < FP_PCOLS;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = acc[i][j][e];
+                        const float s1 = dpp_row<0x101>(a, a);                                             // lane + 1 (lane 15: unused)
+                        const float nx = i < 3 ? dpp_row<0x11e>(a, acc[i < 3 ? i + 1 : 3][j][e]) : a;      // lanes 14, 15 <- lanes 0, 1 of the next fragment
+                        const float s2 = dpp_row<0x102>(nx, a);                                            // lane + 2; lanes 14, 15 keep nx
+                        m[e] = fmaxf(a, fmaxf(s1, s2));
+                    }
+                    // channels (j >> 1) * 32 + fq * 8 + (j & 1) * 4 .. + 3 = 16-byte chunk (j >> 1) * 8 + fq * 2 + (j & 1) of the pixel's 256 bytes
+                    if (producer) *(f32x4*)((unsigned char*)hrow + q * 256 + (((((j >> 1) * 8 + fq * 2 + (j & 1))) ^ (q & 15)) << 4)) = m;
+                }
+            }
+        }
+        if (!pre) {
+            __syncthreads();
+            for (int item = tid; item < PR * FP_PCOLS * 16; item += NT) {
+                const int c16 = item & 15, qq = item >> 4;
+                const int k = qq / FP_PCOLS, j = qq - k * FP_PCOLS;
+                const int py = PR * t + k, px = FP_PCOLS * sidx + j;
+                if (py >= Hp || px >= Wp) continue;
+                f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = FP_ROWS * t - pt + 2 * k + dy;
+                    if ((unsigned)r >= (unsigned)Ho) continue;
+                    const unsigned char* crow = s_c + ((FP_ROWS * t + 2 * k + dy) % RING) * XP_ROW_BYTES;
+                    const f32x4 v = *(const f32x4*)(crow + j * 256 + ((c16 ^ (j & 15)) << 4));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) m[c] = fmaxf(m[c], v[c]);
+                }
+                *(f32x4*)(out + (((size_t)b * Hp + py) * Wp + px) * 64 + c16 * 4) = m;
+            }
+        }
+        idx = nidx;
+        pre = npre;
+    }
+}
+
 // 3x3 stride-2 max-pool, TF 'same' (pad_before = pad_total / 2, padding never wins)
 template <typename scalar, typename vec8>
 __global__ __launch_bounds__(256) void maxpool_kernel(const scalar* __restrict__ in, scalar* __restrict__ out,
@@ -773,6 +977,43 @@ extern "C" int gpp_stem_pool_fused_mfma(const float* in, const void* packed_weig
     else if (which == 1) stem_pool_mfma_kernel<_Float16, f16x8, 8><<<grid, 512, lds, st>>>(in, wp, bias, (_Float16*)out, B, H, W, Ho, Wo, Hp, Wp, pt, pl);
     else if (which == 2) stem_pool_mfma_kernel<__bf16, bf16x8, 4><<<grid, 256, lds, st>>>(in, wp, bias, (__bf16*)out, B, H, W, Ho, Wo, Hp, Wp, pt, pl);
     else stem_pool_mfma_kernel<_Float16, f16x8, 4><<<grid, 256, lds, st>>>(in, wp, bias, (_Float16*)out, B, H, W, Ho, Wo, Hp, Wp, pt, pl);
+    return result();
+}
+
+extern "C" int gpp_stem_pool_fused_x3(const float* in, const void* packed_weight_x3, const float* bias, float* out,
+                                      int B, int H, int W, uint64_t* range_counter, void* stream)
+{
+    if (!in || !packed_weight_x3 || !bias || !out || B <= 0 || H <= 0 || W <= 0) return GPP_ERR_BAD_ARG;
+    if ((uintptr_t)range_counter & 7) return GPP_ERR_ALIGN;
+    if (((uintptr_t)out | (uintptr_t)packed_weight_x3) & 15) return GPP_ERR_ALIGN;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const int Hp = (Ho + 1) / 2, Wp = (Wo + 1) / 2;
+    const int pt = ((Hp - 1) * 2 + 3 - Ho > 0 ? (Hp - 1) * 2 + 3 - Ho : 0) / 2;
+    const int pl = ((Wp - 1) * 2 + 3 - Wo > 0 ? (Wp - 1) * 2 + 3 - Wo : 0) / 2;
+    // 6 conv rows per step (6 wavefronts); GPP_STEM_POOL_X3_ROWS=4: 4.  One workgroup per CU either way (the hi / lo weights alone are 58 KB).
+    static const int rows = [] { const char* e = getenv("GPP_STEM_POOL_X3_ROWS"); return (e && atoi(e) == 4) ? 4 : 6; }();
+    const int pr = rows / 2;
+    const int64_t total = (int64_t)B * ((Wp + FP_PCOLS - 1) / FP_PCOLS) * ((Hp + pr - 1) / pr);
+    if (total >= (1LL << 30)) return GPP_ERR_UNSUPPORTED;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return GPP_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)(total < cus ? total : cus);                  // persistent workgroups
+    hipStream_t st = (hipStream_t)stream;
+    static std::atomic<uint64_t> done[2];
+    const int which = rows == 6 ? 0 : 1;
+    const void* fns[2] = {(const void*)stem_pool_mfma_x3_kernel<6>, (const void*)stem_pool_mfma_x3_kernel<4>};
+    const int lds = xp_lds(rows);
+    if (!(done[which].load(std::memory_order_acquire) & (1ull << (dev & 63)))) {
+        const hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        done[which].fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    unsigned long long* counter = range_counter ? (unsigned long long*)range_counter : gpp_x3_range_counter_f16x3();
+    if (!counter) return GPP_ERR_UNSUPPORTED;
+    const _Float16* wp = (const _Float16*)packed_weight_x3;
+    if (which == 0) stem_pool_mfma_x3_kernel<6><<<grid, 384, lds, st>>>(in, wp, bias, out, B, H, W, Ho, Wo, Hp, Wp, pt, pl, counter);
+    else stem_pool_mfma_x3_kernel<4><<<grid, 256, lds, st>>>(in, wp, bias, out, B, H, W, Ho, Wo, Hp, Wp, pt, pl, counter);
     return result();
 }
 

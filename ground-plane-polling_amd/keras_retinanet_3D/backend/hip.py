@@ -136,6 +136,8 @@ def _declare(lib):
     lib.gpp_x3_range_snapshot_of.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.gpp_stem_conv7x7_bn_relu_x3_rc.restype = c_int
     lib.gpp_stem_conv7x7_bn_relu_x3_rc.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.gpp_stem_pool_fused_x3.restype = c_int
+    lib.gpp_stem_pool_fused_x3.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.gpp_bottleneck_block.restype = c_int
     lib.gpp_bottleneck_block.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), c_int, c_void_p]
     lib.gpp_conv2d_autotune.restype = c_int

@@ -380,18 +380,21 @@ class RetinaNet3D(object):
         H1, W1 = (H + 6 - 7) // 2 + 1, (Wd + 6 - 7) // 2 + 1
         H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
         x = fmap(H2, W2, 64)
-        if self.esz == 2 and os.environ.get('GPP_FUSE_STEM_POOL', '1') != '0':
-            # 16-bit types: conv1 + bn_conv1 + relu + pool1 in one launch, the (B, H1, W1, 64) conv map is never stored
-            # (bit-identical to the two launches: tests/test_stem_gpu.py)
+        stem_x3 = getattr(self, 'stem_x3', False)
+        if (self.esz == 2 or stem_x3) and os.environ.get('GPP_FUSE_STEM_POOL', '1') != '0':
+            # conv1 + bn_conv1 + relu + pool1 in one launch, the (B, H1, W1, 64) conv map is never stored (bit-identical to the two launches:
+            # tests/test_stem_gpu.py).  16-bit types since round 2; the x3 types since round 6 (gpp_stem_pool_fused_x3: the float32 conv map was
+            # 274 MB written + read back at B = 8)
             d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), x.buf.data_ptr(),
-                         C.gpp_storage_dtype(self.dtype), B, H, Wd, None)
+                         hip.GPP_F16X3 if stem_x3 else C.gpp_storage_dtype(self.dtype), B, H, Wd,
+                         plan.range_slot.data_ptr() if self.dtype == 'f16x3' else None)
             plan.add(OP_STEM_POOL, d, 'conv1+pool1', flops=2.0 * B * H1 * W1 * 147 * 64)
             plan.touch(d, [Plan.span_of(plan.images)], [Plan.span(x)])
             plan.stem_out = None
         else:
             stem = fmap(H1, W1, 64)
             d = StemDesc(plan.images.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(), stem.buf.data_ptr(),
-                         hip.GPP_F16X3 if getattr(self, 'stem_x3', False) else C.gpp_storage_dtype(self.dtype), B, H, Wd,
+                         hip.GPP_F16X3 if stem_x3 else C.gpp_storage_dtype(self.dtype), B, H, Wd,
                          plan.range_slot.data_ptr() if self.dtype == 'f16x3' else None)
             plan.add(OP_STEM, d, 'conv1', flops=2.0 * B * H1 * W1 * 147 * 64)
             plan.touch(d, [Plan.span_of(plan.images)], [Plan.span(stem)])

@@ -294,6 +294,11 @@ int gpp_stem_conv7x7_bn_relu_x3(const float* in, const void* packed_weight_x3, c
  * the caller's 8-byte slot instead of the library's per-device counter (NULL = that one: the function above) */
 int gpp_stem_conv7x7_bn_relu_x3_rc(const float* in, const void* packed_weight_x3, const float* bias, float* out,
                                    int B, int H, int W, uint64_t* range_counter, void* stream);
+/* conv1 + bn_conv1 + ReLU + pool1 of the x3 types in ONE launch: out is the POOLED float32 map (B, Hp, Wp, 64); the (B, Ho, Wo, 64) float32
+ * conv map (274 MB at B = 8, 402 x 1333) is never written.  Bit-identical to gpp_stem_conv7x7_bn_relu_x3_rc followed by
+ * gpp_maxpool3x3s2_same(GPP_F32), and the range events of the conv map are counted as there (same count). */
+int gpp_stem_pool_fused_x3(const float* in, const void* packed_weight_x3, const float* bias, float* out,
+                           int B, int H, int W, uint64_t* range_counter, void* stream);
 /* dtype GPP_BF16X3 = a pre-split map (gpp_conv_desc.x3_split): ReLU on the [hi | lo] pairs (count in float32-sized elements, a
    multiple of 32) */
 int gpp_relu(const void* in, void* out, int dtype, int64_t count, void* stream);
@@ -397,7 +402,7 @@ int gpp_pack_detections(const float* boxes, const float* dims, const float* scor
 #define GPP_OP_DETECT_EMIT 10
 /* (11: the three-layer tail of round 2, removed in round 3 -- measured slower than its separate launches) */
 #define GPP_OP_DETECT_OSF 12             /* gpp_detect_desc -> gpp_detect_osf_f32 */
-#define GPP_OP_STEM_POOL 13              /* gpp_stem_desc with out = the pooled map -> gpp_stem_pool_fused_mfma */
+#define GPP_OP_STEM_POOL 13              /* gpp_stem_desc with out = the pooled map -> gpp_stem_pool_fused_mfma (GPP_BF16 / GPP_F16) / gpp_stem_pool_fused_x3 (GPP_F16X3 / GPP_BF16X3) */
 #define GPP_OP_BOTTLENECK_BLOCK 16       /* gpp_block_desc -> gpp_bottleneck_block */
 /* (14, 15: the Winograd F(2, 3) form of the tower layers of round 5 -- built, measured at -2 % of the step, shelved in round 6:
    tools/experiments/winograd/) */

@@ -110,6 +110,55 @@ def test_fused_stem_pool_equals_the_two_launches(B, H, W, dtype, tdt):
     assert torch.equal(a, b), 'differs at {} of {} elements'.format(int((a != b).sum()), a.numel())
 
 
+@pytest.mark.parametrize('big', [False, True])
+@pytest.mark.parametrize('B,H,W', [(2, 37, 53), (1, 40, 56), (3, 38, 55), (1, 7, 9), (2, 96, 160), (1, 127, 211), (1, 270, 500), (2, 402, 1333), (1, 250, 249), (1, 252, 251)])
+def test_fused_x3_stem_pool_equals_the_two_launches(B, H, W, big):
+    """ gpp_stem_pool_fused_x3 (conv1 + bn + relu + pool1 of the x3 types in one launch, the horizontal half of the pool taken in the accumulator
+    lanes) == gpp_stem_conv7x7_bn_relu_x3_rc followed by gpp_maxpool3x3s2_same(GPP_F32), bit for bit, on the shapes of the 16-bit test plus
+    maps whose last strip is full (Wp = 62 / 63); and it counts the range events of the conv map exactly as the unfused stem does
+    (`big`: weights that drive part of the conv map beyond 65504 -- in the overlap columns of two strips and in carried rows too) """
+    g = torch.Generator().manual_seed(H * W + B)
+    x = torch.rand((B, H, W, 3), generator=g) * 255.0 - 120.0
+    k = torch.randn((7, 7, 3, 64), generator=g) * (40.0 if big else 0.05)
+    bias = torch.randn((64,), generator=g)
+    dev = torch.device('cuda')
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Ho + 1) // 2, (Wo + 1) // 2
+    xd, bd = x.to(dev).contiguous(), bias.to(dev)
+    packed = hip.pack_stem_weights_x3(k.reshape(147, 64).numpy(), dev)
+    conv = torch.full((B, Ho, Wo, 64), float('nan'), dtype=torch.float32, device=dev)
+    want = torch.full((B, Hp, Wp, 64), float('nan'), dtype=torch.float32, device=dev)
+    got = torch.full((B, Hp, Wp, 64), float('nan'), dtype=torch.float32, device=dev)
+    slots = torch.zeros((2,), dtype=torch.int64, device=dev)
+    lib = hip.lib()
+    hip.check(lib.gpp_stem_conv7x7_bn_relu_x3_rc(hip.ptr(xd), hip.ptr(packed), hip.ptr(bd), hip.ptr(conv), B, H, W, slots.data_ptr(), hip.stream_ptr()))
+    hip.check(lib.gpp_maxpool3x3s2_same(hip.ptr(conv), hip.ptr(want), hip.GPP_F32, B, Ho, Wo, 64, hip.stream_ptr()))
+    hip.check(lib.gpp_stem_pool_fused_x3(hip.ptr(xd), hip.ptr(packed), hip.ptr(bd), hip.ptr(got), B, H, W, slots.data_ptr() + 8, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    a, b = got.view(torch.int32).cpu(), want.view(torch.int32).cpu()
+    assert not torch.isnan(want).any()
+    assert torch.equal(a, b), 'differs at {} of {} elements'.format(int((a != b).sum()), a.numel())
+    counts = slots.cpu().tolist()
+    assert counts[0] == counts[1] and (counts[0] > 0) == big, counts
+    if big:                # one event per (pixel, group of 8 channels = what one lane stores) of the conv map with a value beyond the half range
+        assert counts[0] == int((conv.view(B, Ho, Wo, 8, 8) > 65504.0).any(dim=-1).sum())
+
+
+def test_fused_x3_stem_pool_arguments():
+    dev = torch.device('cuda')
+    x = torch.zeros((1, 16, 16, 3), device=dev)
+    w = torch.zeros((2 * 64 * 232 + 128,), dtype=torch.float16, device=dev)
+    b = torch.zeros((64,), device=dev)
+    out = torch.zeros((1, 4, 4, 64), device=dev)
+    lib = hip.lib()
+    assert lib.gpp_stem_pool_fused_x3(hip.ptr(x), hip.ptr(w), hip.ptr(b), hip.ptr(out), 1, 16, 16, None, hip.stream_ptr()) == 0
+    assert lib.gpp_stem_pool_fused_x3(None, hip.ptr(w), hip.ptr(b), hip.ptr(out), 1, 16, 16, None, hip.stream_ptr()) == -1
+    assert lib.gpp_stem_pool_fused_x3(hip.ptr(x), hip.ptr(w), hip.ptr(b), hip.ptr(out), 0, 16, 16, None, hip.stream_ptr()) == -1
+    assert lib.gpp_stem_pool_fused_x3(hip.ptr(x), hip.ptr(w), hip.ptr(b), out.data_ptr() + 4, 1, 16, 16, None, hip.stream_ptr()) == -3
+    assert lib.gpp_stem_pool_fused_x3(hip.ptr(x), hip.ptr(w), hip.ptr(b), hip.ptr(out), 1, 16, 16, out.data_ptr() + 4, hip.stream_ptr()) == -3
+    torch.cuda.synchronize()
+
+
 def test_fused_stem_pool_rejects_float32():
     dev = torch.device('cuda')
     x = torch.zeros((1, 16, 16, 3), device=dev)
