@@ -380,12 +380,14 @@ def main():
     wait_pending()                                             # the last gather completes inside the timed region
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0                     # this rank alone, before it waits for the others
-    monitor.__exit__(None, None, None)
-    device_state = monitor.summary()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # (the sampler is stopped AFTER the clock is read: joining its thread waits for a sysfs read in flight -- 2 - 4 ms, which rounds 3 - 6 had inside
+    # the bracket: 0.4 % of a 100-step region, 1 % of the 30-step default; the repeats below never had it, hence their higher rates in those rounds' lines)
+    monitor.__exit__(None, None, None)
+    device_state = monitor.summary()
     per_rank = None
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
