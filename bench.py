@@ -364,6 +364,10 @@ def main():
         pending.append(work)
         return out
 
+    # (the sampler is BUILT here, before the warm-up: finding the card's hwmon files walks sysfs for tens of milliseconds, and a device left idle that
+    # long between the warm-up and the timed region starts the region from its idle clocks -- see DESIGN 6)
+    from keras_retinanet_3D.utils import devmon
+    monitor = devmon.Sampler(local_rank if distributed else 0, period=float(os.environ.get('GPP_DEVMON_PERIOD_S', '0.02')))     # (a thread reading sysfs files: no GPU call)
     for i in range(args.warmup):
         out = step(warm=i + 1)
     wait_pending()
@@ -371,8 +375,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     gather_wait_s[0] = 0.0
-    from keras_retinanet_3D.utils import devmon
-    monitor = devmon.Sampler(local_rank if distributed else 0, period=float(os.environ.get('GPP_DEVMON_PERIOD_S', '0.02')))     # (a thread reading sysfs files: no GPU call)
     monitor.__enter__()
     t0 = time.perf_counter()
     for k in range(args.steps):

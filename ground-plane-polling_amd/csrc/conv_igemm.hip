@@ -357,12 +357,12 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
     const int tile_in = desc->tile_hint;
     float best = 1e30f;
     int best_tile = tile_in, rc = GPP_OK;
-    auto time_one = [&](int tile, float* us) -> int {
+    auto time_one = [&](int tile, float* us, int reps = 2) -> int {
         desc->tile_hint = tile;
         int r = gpp_conv2d_igemm(desc, stream);                      // warm-up (and validity of this choice)
         if (r != GPP_OK) return r;
         float t_best = 1e30f;
-        for (int rep = 0; rep < 2; ++rep) {
+        for (int rep = 0; rep < reps; ++rep) {
             (void)hipEventRecord(e0, st);
             for (int i = 0; i < iters; ++i) (void)gpp_conv2d_igemm(desc, stream);
             (void)hipEventRecord(e1, st);
@@ -375,12 +375,31 @@ extern "C" int gpp_conv2d_autotune(gpp_conv_desc* desc, int iters, void* stream,
         *us = t_best * 1000.0f / iters;
         return GPP_OK;
     };
+    float second = 1e30f;
+    int second_tile = -1;
     for (int tile : kTiles) {
         if (!tile_is_candidate(desc, tile)) continue;
         float us = 0.0f;
         int r = time_one(tile, &us);
         if (r != GPP_OK) { if (tile == 0) { rc = r; break; } continue; }
-        if (us < best) { best = us; best_tile = tile; }
+        if (us < best) { second = best; second_tile = best_tile; best = us; best_tile = tile; }
+        else if (us < second) { second = us; second_tile = tile; }
+    }
+    // A play-off when the two fastest are within 5 %: the sweep times its candidates one after the other while the board's clock settles under the
+    // load (a power-bound layer runs 2 - 4 % faster in the first tenths of a second), so its order can decide a close call -- round 6 saw one of the
+    // three identical regression-tower layers take the uniform 256 x 256 grid (841 us) beside two that took the mixed-height one (806 - 820).
+    // Three alternating rounds, the sum decides.
+    if (rc == GPP_OK && second_tile >= 0 && second_tile != best_tile && second <= best * 1.05f) {
+        float sum_a = 0.0f, sum_b = 0.0f;
+        bool ok = true;
+        for (int round = 0; round < 3 && ok; ++round) {
+            float a = 0.0f, b = 0.0f;
+            ok = time_one(best_tile, &a, 1) == GPP_OK && time_one(second_tile, &b, 1) == GPP_OK;
+            sum_a += a;
+            sum_b += b;
+        }
+        if (ok && sum_b < sum_a) { best_tile = second_tile; best = sum_b / 3.0f; }
+        else if (ok) best = sum_a / 3.0f;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
