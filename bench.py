@@ -368,6 +368,9 @@ def main():
     # long between the warm-up and the timed region starts the region from its idle clocks -- see DESIGN 6)
     from keras_retinanet_3D.utils import devmon
     monitor = devmon.Sampler(local_rank if distributed else 0, period=float(os.environ.get('GPP_DEVMON_PERIOD_S', '0.02')))     # (a thread reading sysfs files: no GPU call)
+    if distributed:
+        dist.barrier()          # the ranks leave plan build + tuning seconds apart: without this the early ones would sit idle at the barrier BEHIND the warm-up
+    #                             and start the timed region from idle clocks (the same ~3.5 ms, on every rank but the last)
     for i in range(args.warmup):
         out = step(warm=i + 1)
     wait_pending()
