@@ -144,6 +144,19 @@ def test_fused_x3_stem_pool_equals_the_two_launches(B, H, W, big):
         assert counts[0] == int((conv.view(B, Ho, Wo, 8, 8) > 65504.0).any(dim=-1).sum())
 
 
+def test_fused_x3_stem_pool_four_row_form_in_a_child_process():
+    """ GPP_STEM_POOL_X3_ROWS=4 (4 wavefronts, 4 conv rows per step; read once per process): the measured alternative of the shipped 6-row form gives the
+    same bytes -- tools/bench_stem.py in a child process on a map of several strips and row blocks """
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPP_STEM_POOL_X3_ROWS='4')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_stem.py'), '2', '150', '333'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         universal_newlines=True, timeout=300).stdout
+    assert 'bytes equal: True' in out and 'GPP_STEM_POOL_X3_ROWS=4' in out, out[-800:]
+
+
 def test_fused_x3_stem_pool_arguments():
     dev = torch.device('cuda')
     x = torch.zeros((1, 16, 16, 3), device=dev)
